@@ -1,0 +1,263 @@
+/*
+ * breed_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See breed_oracle.h for scope, citations and the "parity unpinned" statement.
+ *
+ * Written for clarity, not speed: one scalar Threefry call per counter pair,
+ * explicit float compare, explicit running XOR.  OpenMP over crosses only.
+ */
+#include "breed_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Threefry-2x32-20                                                         */
+/* ------------------------------------------------------------------------ */
+
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+void bo_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                     uint32_t *o0, uint32_t *o1) {
+  static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int blk = 0; blk < 5; ++blk) {
+    const int *rot = (blk & 1) ? R + 4 : R;
+    for (int i = 0; i < 4; ++i) {
+      x0 += x1;
+      x1 = rotl32(x1, rot[i]);
+      x1 ^= x0;
+    }
+    x0 += ks[(blk + 1) % 3];
+    x1 += ks[(blk + 2) % 3] + (uint32_t)(blk + 1);
+  }
+  *o0 = x0;
+  *o1 = x1;
+}
+
+void bo_key_from_seed(uint64_t seed, uint32_t key[2]) {
+  key[0] = 0u; /* x64 disabled: the high word is shifted out */
+  key[1] = (uint32_t)(seed & 0xFFFFFFFFu);
+}
+
+/* jax `threefry_2x32(key, count)` for count = iota(n): the counter vector is
+ * padded to even length with a 0, cut in two halves (x0 = first, x1 = second),
+ * hashed pairwise, and the two output halves are concatenated again. */
+static void threefry_iota(const uint32_t key[2], int64_t n, uint32_t *out) {
+  int64_t L = n + (n & 1), h = L / 2;
+  for (int64_t i = 0; i < h; ++i) {
+    uint32_t c0 = (uint32_t)i;
+    uint32_t c1 = (i + h < n) ? (uint32_t)(i + h) : 0u; /* the pad counter */
+    uint32_t o0, o1;
+    bo_threefry2x32(key[0], key[1], c0, c1, &o0, &o1);
+    out[i] = o0;
+    if (i + h < n) out[i + h] = o1;
+  }
+}
+
+void bo_random_bits(const uint32_t key[2], int64_t n, uint32_t *out) {
+  threefry_iota(key, n, out);
+}
+
+void bo_split(const uint32_t key[2], int64_t num, uint32_t *out) {
+  /* counts = iota(2*num); result reshaped (num, 2) */
+  threefry_iota(key, 2 * num, out);
+}
+
+float bo_uniform_f32(uint32_t bits) {
+  uint32_t w = (bits >> 9) | 0x3F800000u;
+  float f;
+  memcpy(&f, &w, 4);
+  f -= 1.0f;
+  return f < 0.0f ? 0.0f : f; /* lax.max(minval, ...) */
+}
+
+uint32_t bo_threshold23(float r) {
+  /* u = k * 2^-23 with k = bits >> 9 (exact in f32).  u < r  <=>  k < r*2^23
+   * <=>  k < ceil(r*2^23) for k integer.  r*2^23 is an exact f32 scaling. */
+  if (!(r > 0.0f)) return 0u; /* r <= 0 or NaN: never */
+  if (r >= 1.0f) return 1u << 23; /* always (k <= 2^23 - 1) */
+  return (uint32_t)ceil((double)r * 8388608.0);
+}
+
+void bo_meiosis_mask(const uint32_t rec_key[2], const float *r, int64_t M,
+                     uint8_t *mask) {
+  uint32_t *bits = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(M > 0 ? M : 1));
+  bo_random_bits(rec_key, M, bits);
+  uint8_t run = 0;
+  for (int64_t m = 0; m < M; ++m) {
+    uint8_t site = bo_uniform_f32(bits[m]) < r[m];
+    run ^= site; /* inclusive cumulative XOR */
+    mask[m] = run;
+  }
+  free(bits);
+}
+
+/* ------------------------------------------------------------------------ */
+/* permutation / founders / top-k                                           */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  uint32_t k;
+  int32_t v;
+  int32_t pos; /* current position: makes qsort stable */
+} kv_t;
+
+static int kv_cmp(const void *a, const void *b) {
+  const kv_t *x = (const kv_t *)a, *y = (const kv_t *)b;
+  if (x->k != y->k) return x->k < y->k ? -1 : 1;
+  return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+
+void bo_permutation(const uint32_t key_in[2], int64_t N, int32_t *out) {
+  /* jax/_src/random.py `_shuffle`: repeated stable sorts by fresh 32-bit keys */
+  uint32_t key[2] = {key_in[0], key_in[1]};
+  double sz = N > 1 ? (double)N : 1.0;
+  int rounds = (int)ceil(3.0 * log(sz) / log(4294967295.0));
+  kv_t *kv = (kv_t *)malloc(sizeof(kv_t) * (size_t)(N > 0 ? N : 1));
+  uint32_t *bits = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(N > 0 ? N : 1));
+  for (int64_t i = 0; i < N; ++i) out[i] = (int32_t)i;
+  for (int rd = 0; rd < rounds; ++rd) {
+    uint32_t two[4];
+    bo_split(key, 2, two);
+    key[0] = two[0];
+    key[1] = two[1];
+    bo_random_bits(&two[2], N, bits);
+    for (int64_t i = 0; i < N; ++i) {
+      kv[i].k = bits[i];
+      kv[i].v = out[i];
+      kv[i].pos = (int32_t)i;
+    }
+    qsort(kv, (size_t)N, sizeof(kv_t), kv_cmp);
+    for (int64_t i = 0; i < N; ++i) out[i] = kv[i].v;
+  }
+  free(kv);
+  free(bits);
+}
+
+void bo_founders(uint32_t env_key[2], int64_t E, int64_t N, int64_t n, int32_t *out) {
+  uint32_t *keys = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)(E + 1));
+  int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  bo_split(env_key, E + 1, keys);
+  env_key[0] = keys[0];
+  env_key[1] = keys[1];
+  for (int64_t e = 0; e < E; ++e) {
+    bo_permutation(&keys[2 * (e + 1)], N, perm);
+    memcpy(out + e * n, perm, sizeof(int32_t) * (size_t)n);
+  }
+  free(keys);
+  free(perm);
+}
+
+typedef struct {
+  float s;
+  int32_t i;
+} si_t;
+
+static int si_cmp(const void *a, const void *b) {
+  const si_t *x = (const si_t *)a, *y = (const si_t *)b;
+  if (x->s != y->s) return x->s > y->s ? -1 : 1;
+  return x->i < y->i ? -1 : (x->i > y->i);
+}
+
+void bo_topk(const float *scores, int64_t n, int64_t k, int32_t *out) {
+  si_t *a = (si_t *)malloc(sizeof(si_t) * (size_t)(n > 0 ? n : 1));
+  for (int64_t i = 0; i < n; ++i) {
+    a[i].s = scores[i];
+    a[i].i = (int32_t)i;
+  }
+  qsort(a, (size_t)n, sizeof(si_t), si_cmp);
+  for (int64_t i = 0; i < k; ++i) out[i] = a[i].i;
+  free(a);
+}
+
+/* ------------------------------------------------------------------------ */
+/* cross / GEBV / reward                                                    */
+/* ------------------------------------------------------------------------ */
+
+int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
+             int64_t n_out, int64_t M, const float *r, uint32_t key[2],
+             int rng_mode, uint8_t *out, uint8_t *masks) {
+  /* [EXTERNAL/UNVERIFIED] chromax.Simulator.cross key plumbing:
+   *   keys = split(sim_key, 2*B + 1); sim_key <- keys[0];
+   *   gamete (b, p) uses keys[1 + 2*b + p];
+   *   inside meiosis: rec_key = split(gamete_key, 2)[0].
+   * B = n_out when the key is shared by all envs, E*n_out otherwise. */
+  for (int64_t j = 0; j < E * n_out * 2; ++j)
+    if (idx[j] < 0 || idx[j] >= n_pool) return -1;
+
+  int64_t B = rng_mode == 0 ? n_out : E * n_out;
+  uint32_t *keys = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)(2 * B + 1));
+  bo_split(key, 2 * B + 1, keys);
+  key[0] = keys[0];
+  key[1] = keys[1];
+
+  int64_t row = 2 * M;
+#pragma omp parallel
+  {
+    uint8_t *mask = (uint8_t *)malloc((size_t)(M > 0 ? M : 1));
+#pragma omp for schedule(static)
+    for (int64_t c = 0; c < E * n_out; ++c) {
+      int64_t e = c / n_out, i = c % n_out;
+      int64_t b = rng_mode == 0 ? i : c;
+      for (int p = 0; p < 2; ++p) {
+        uint32_t two[4];
+        bo_split(&keys[2 * (1 + 2 * b + p)], 2, two);
+        bo_meiosis_mask(two, r, M, mask); /* two[0..1] = rec key */
+        const uint8_t *par = pool + (e * n_pool + idx[2 * c + p]) * row;
+        uint8_t *o = out + c * row;
+        for (int64_t m = 0; m < M; ++m) o[2 * m + p] = par[2 * m + mask[m]];
+        if (masks) memcpy(masks + (2 * c + p) * M, mask, (size_t)M);
+      }
+    }
+    free(mask);
+  }
+  free(keys);
+  return 0;
+}
+
+void bo_gebv(const uint8_t *pop, int64_t rows, int64_t M, const float *effects,
+             int64_t T, float *out32, double *out64) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < rows; ++i) {
+    const uint8_t *g = pop + i * 2 * M;
+    for (int64_t t = 0; t < T; ++t) {
+      double acc = 0.0;
+      for (int64_t m = 0; m < M; ++m) {
+        int d = g[2 * m] + g[2 * m + 1];
+        acc += (double)d * (double)effects[m * T + t];
+      }
+      if (out32) out32[i * T + t] = (float)acc;
+      if (out64) out64[i * T + t] = acc;
+    }
+  }
+}
+
+void bo_reward_max(const float *gebv, int64_t E, int64_t nT, float *out) {
+  for (int64_t e = 0; e < E; ++e) {
+    float mx = -INFINITY;
+    for (int64_t j = 0; j < nT; ++j)
+      if (gebv[e * nT + j] > mx) mx = gebv[e * nT + j];
+    out[e] = mx;
+  }
+}
+
+int bo_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+void bo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

@@ -1,0 +1,182 @@
+"""NumPy restatement of the reference's op graph (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+Deliberately *unfused*, array-at-a-time, like the reference's CPU execution through
+chromax/JAX: materialised parent gather (``breedgym/vector/vec_env.py:89-90``),
+``uniform(M) < r``, cumulative XOR, ``take_along_axis``, ``sum(-1) @ effects``
+(``scripts/optimize_diff_cross.py:16-17``).  It is the readable specification, the
+second opinion for the C oracle, and the "B1" CPU baseline of BASELINE.md.
+
+PARITY UNPINNED: chromax/jax are not installed; the key plumbing of
+``chromax.Simulator.cross`` is restated from its published source from memory and is
+marked [EXTERNAL/UNVERIFIED].
+"""
+import math
+
+import numpy as np
+
+_R = (13, 15, 26, 6, 17, 29, 16, 24)
+_U32 = np.uint32
+
+
+def _rotl(x, r):
+    return (x << _U32(r)) | (x >> _U32(32 - r))
+
+
+def threefry2x32(key, c0, c1):
+    """Threefry-2x32-20 on uint32 arrays c0, c1 (same shape) with one key pair."""
+    with np.errstate(over="ignore"):
+        k0, k1 = _U32(key[0]), _U32(key[1])
+        ks = (k0, k1, k0 ^ k1 ^ _U32(0x1BD11BDA))
+        x0 = np.asarray(c0, _U32) + ks[0]
+        x1 = np.asarray(c1, _U32) + ks[1]
+        for blk in range(5):
+            rot = _R[4:] if blk & 1 else _R[:4]
+            for r in rot:
+                x0 = x0 + x1
+                x1 = _rotl(x1, r)
+                x1 = x1 ^ x0
+            x0 = x0 + ks[(blk + 1) % 3]
+            x1 = x1 + ks[(blk + 2) % 3] + _U32(blk + 1)
+    return x0, x1
+
+
+def key_from_seed(seed):
+    return np.array([0, int(seed) & 0xFFFFFFFF], _U32)
+
+
+def _threefry_iota(key, n):
+    """jax `threefry_2x32(key, iota(n))`: pad to even with a 0 counter, hash the two halves."""
+    cnt = np.arange(n, dtype=_U32)
+    if n % 2:
+        cnt = np.concatenate([cnt, np.zeros(1, _U32)])
+    h = len(cnt) // 2
+    o0, o1 = threefry2x32(key, cnt[:h], cnt[h:])
+    return np.concatenate([o0, o1])[:n]
+
+
+def random_bits(key, n):
+    return _threefry_iota(key, n)
+
+
+def split(key, num):
+    return _threefry_iota(key, 2 * num).reshape(num, 2)
+
+
+def uniform(key, n):
+    bits = random_bits(key, n)
+    f = ((bits >> _U32(9)) | _U32(0x3F800000)).view(np.float32) - np.float32(1.0)
+    return np.maximum(np.float32(0.0), f)
+
+
+def permutation(key, N):
+    """jax.random.permutation(key, N): `_shuffle` = repeated stable sort by random 32-bit keys."""
+    rounds = int(math.ceil(3 * math.log(max(1, N)) / math.log(2**32 - 1)))
+    x = np.arange(N, dtype=np.int32)
+    key = np.asarray(key, _U32)
+    for _ in range(rounds):
+        key, sub = split(key, 2)
+        x = x[np.argsort(random_bits(sub, N), kind="stable")]
+    return x
+
+
+def founders(env_key, E, N, n):
+    """VecBreedGym.reset founder draw (vec_env.py:22-27,120-128)."""
+    keys = split(env_key, E + 1)
+    idx = np.stack([permutation(keys[1 + e], N)[:n] for e in range(E)])
+    return idx, keys[0].copy()
+
+
+def meiosis(individual, r, gamete_key):
+    """[EXTERNAL/UNVERIFIED] chromax.functional._meiosis: (M,2) -> gamete (M,)."""
+    rec_key = split(gamete_key, 2)[0]
+    sites = uniform(rec_key, len(r)) < r
+    mask = np.logical_xor.accumulate(sites).astype(np.int8)
+    return np.take_along_axis(individual, mask[:, None], axis=-1)[:, 0], mask
+
+
+def cross(parents, r, sim_key):
+    """[EXTERNAL/UNVERIFIED] chromax.Simulator.cross on materialised parents (n,2,M,2).
+
+    Returns (offspring (n,M,2), new_sim_key, masks (n,2,M))."""
+    n = len(parents)
+    keys = split(sim_key, 2 * n + 1)
+    out = np.empty((n, parents.shape[2], 2), parents.dtype)
+    masks = np.empty((n, 2, parents.shape[2]), np.uint8)
+    for i in range(n):
+        for p in range(2):
+            out[i, :, p], masks[i, p] = meiosis(parents[i, p], r, keys[1 + 2 * i + p])
+    return out, keys[0].copy(), masks
+
+
+def vec_step_cross(populations, actions, r, sim_key, rng_mode=0):
+    """vec_env.py:88-91: gather parents, then vmap(cross) over envs.
+
+    rng_mode 0 reproduces vmap over an un-batched simulator key: every env gets the
+    same gamete keys.  rng_mode 1 treats the E*n crosses as one flat batch."""
+    E, n = actions.shape[:2]
+    parents = populations[np.arange(E)[:, None, None], actions]  # (E,n,2,M,2) materialised
+    if rng_mode == 0:
+        outs, newkey = [], None
+        for e in range(E):
+            o, newkey, _ = cross(parents[e], r, sim_key)
+            outs.append(o)
+        return np.stack(outs), newkey
+    flat, newkey, _ = cross(parents.reshape(E * n, 2, *parents.shape[3:]), r, sim_key)
+    return flat.reshape(E, n, *flat.shape[1:]), newkey
+
+
+def gebv(pop, effects):
+    """sum over ploidy, dot with marker effects; f64 so it can arbitrate tolerances."""
+    dosage = pop.astype(np.int8).sum(-1, dtype=np.int8)
+    return dosage.astype(np.float64) @ np.asarray(effects, np.float64)
+
+
+def reward_max(g):
+    return np.max(g, axis=(1, 2))
+
+
+def topk(scores, k):
+    return np.argsort(-np.asarray(scores, np.float32), kind="stable")[:k].astype(np.int32)
+
+
+# ---- fully vectorised variant used as the "B1" CPU baseline ------------------------------
+
+
+def cross_batched(parents, r, sim_key):
+    """Same result as `cross`, array-at-a-time over all crosses (the unfused reference graph)."""
+    n, _, M, _ = parents.shape
+    keys = split(sim_key, 2 * n + 1)
+    gk = keys[1:].reshape(n * 2, 2)
+    # rec_key = split(gk, 2)[0] = (TF(gk,(0,2))[0], TF(gk,(1,3))[0]) for every gamete key
+    with np.errstate(over="ignore"):
+        rk = np.empty_like(gk)
+        for w, (c0, c1) in enumerate(((0, 2), (1, 3))):
+            rk[:, w] = _tf_multi(gk, np.full(len(gk), c0, _U32), np.full(len(gk), c1, _U32))[0]
+        L = M + (M & 1)
+        h = L // 2
+        c0 = np.arange(h, dtype=_U32)
+        c1 = np.where(c0 + h < M, c0 + h, 0).astype(_U32)
+        o0, o1 = _tf_multi(rk[:, None, :], c0[None, :], c1[None, :])
+        bits = np.concatenate([o0, o1], axis=1)[:, :M]
+    u = ((bits >> _U32(9)) | _U32(0x3F800000)).view(np.float32) - np.float32(1.0)
+    sites = u < r[None, :]
+    mask = np.logical_xor.accumulate(sites, axis=1).reshape(n, 2, M)
+    gam = np.take_along_axis(parents, mask[..., None].astype(np.int64), axis=-1)[..., 0]
+    return np.ascontiguousarray(gam.transpose(0, 2, 1)), keys[0].copy()
+
+
+def _tf_multi(keys, c0, c1):
+    """threefry with an array of keys (..., 2) broadcast against counters."""
+    k0, k1 = keys[..., 0], keys[..., 1]
+    ks = (k0, k1, k0 ^ k1 ^ _U32(0x1BD11BDA))
+    x0 = c0 + ks[0]
+    x1 = c1 + ks[1]
+    for blk in range(5):
+        rot = _R[4:] if blk & 1 else _R[:4]
+        for r in rot:
+            x0 = x0 + x1
+            x1 = _rotl(x1, r)
+            x1 = x1 ^ x0
+        x0 = x0 + ks[(blk + 1) % 3]
+        x1 = x1 + ks[(blk + 2) % 3] + _U32(blk + 1)
+    return x0, x1
