@@ -1,0 +1,127 @@
+"""ctypes binding of libbreedhip.so (the C ABI in include/breedhip.h).
+
+The library is HIP-only.  If it has not been built, or no gfx950 device is visible, the
+compute entry points raise -- there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_ROOT = _PKG.parent
+LIB_PATH = _PKG / "libbreedhip.so"
+_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "threefry.h")] + [
+    _ROOT / "include" / "breedhip.h"
+]
+
+BH_OK = 0
+BH_ERR_BAD_ARG = -1
+BH_ERR_OOM = -2
+BH_ERR_HIP = -3
+BH_ERR_UNSUPPORTED = -4
+BH_ERR_NO_DEVICE = -5
+BH_ERR_BAD_GENOTYPE = -6
+
+RNG_SHARED_ENVS = 0
+RNG_INDEPENDENT = 1
+
+
+class BreedHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbreedhip error {code}: {msg}")
+        self.code = code
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    """Compile libbreedhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if not force and LIB_PATH.exists():
+        newest = max(p.stat().st_mtime for p in _SOURCES)
+        if LIB_PATH.stat().st_mtime >= newest:
+            return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libbreedhip.so")
+    cmd = [
+        hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall",
+        f"-I{_ROOT / 'include'}", "-o", str(LIB_PATH), str(_PKG / "csrc" / "breedhip.hip"),
+    ]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+_c = ctypes
+_vp, _i64, _int = _c.c_void_p, _c.c_int64, _c.c_int
+_u32p = _c.POINTER(_c.c_uint32)
+_i32p = _c.POINTER(_c.c_int32)
+_f32p = _c.POINTER(_c.c_float)
+
+# name -> (restype, argtypes); kept in step with include/breedhip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "bh_version": (_c.c_char_p, []),
+    "bh_last_error": (_c.c_char_p, []),
+    "bh_device_count": (_int, [_c.POINTER(_int)]),
+    "bh_create": (_int, [_int, _i64, _i64, _f32p, _f32p, _c.POINTER(_vp)]),
+    "bh_destroy": (_int, [_vp]),
+    "bh_set_stream": (_int, [_vp, _vp]),
+    "bh_sync": (_int, [_vp]),
+    "bh_row_pitch": (_i64, [_vp]),
+    "bh_n_markers": (_i64, [_vp]),
+    "bh_n_traits": (_i64, [_vp]),
+    "bh_max_markers": (_i64, []),
+    "bh_alloc": (_int, [_vp, _i64, _c.POINTER(_vp)]),
+    "bh_free": (_int, [_vp, _vp]),
+    "bh_memcpy_h2d": (_int, [_vp, _vp, _vp, _i64]),
+    "bh_memcpy_d2h": (_int, [_vp, _vp, _vp, _i64]),
+    "bh_upload_population": (_int, [_vp, _vp, _i64, _vp, _int]),
+    "bh_download_population": (_int, [_vp, _vp, _i64, _vp]),
+    "bh_cross": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp]),
+    "bh_gather": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "bh_gebv": (_int, [_vp, _vp, _i64, _vp]),
+    "bh_reward_max": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "bh_topk": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
+    "bh_key_split": (_int, [_u32p, _i64, _u32p]),
+    "bh_permutation": (_int, [_u32p, _i64, _i32p]),
+    "bh_founders": (_int, [_u32p, _i64, _i64, _i64, _i32p]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load libbreedhip.so; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(needs hipcc).  breedgym_amd has no CPU fallback."
+            )
+        L = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == BH_OK:
+        return
+    msg = lib().bh_last_error().decode("utf-8", "replace")
+    if rc in (BH_ERR_BAD_ARG, BH_ERR_BAD_GENOTYPE):
+        raise ValueError(f"libbreedhip: {msg}")
+    if rc == BH_ERR_OOM:
+        raise MemoryError(f"libbreedhip: {msg}")
+    raise BreedHipError(rc, msg)
+
+
+def device_count() -> int:
+    n = _int(0)
+    rc = lib().bh_device_count(ctypes.byref(n))
+    return n.value if rc == BH_OK else 0

@@ -1,0 +1,531 @@
+// libbreedhip.so -- host side of the C ABI declared in include/breedhip.h.
+// HIP only: there is no CPU fallback in this library; without a gfx950 device every
+// compute entry point fails with BH_ERR_NO_DEVICE / BH_ERR_HIP.
+#include "breedhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "row_kernels.h"
+#include "threefry.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define BH_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(e_ == hipErrorOutOfMemory ? BH_ERR_OOM : BH_ERR_HIP, "%s failed: %s",  \
+                  #call, hipGetErrorString(e_));                                         \
+  } while (0)
+
+constexpr int kMaxFusedTraits = 8;
+constexpr int kTopkChunk = 16384;  // candidates one block sorts in LDS (128 KiB of keys)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct bh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t M = 0, T = 0, pitch = 0;
+  int32_t half = 0, nwh = 0, nw = 0, nvec = 0;
+  int64_t effPitch = 0;
+  uint32_t *d_thrA = nullptr, *d_thrB = nullptr;
+  double *d_eff = nullptr;  // (T, effPitch)
+  // top-k scratch
+  float *d_cand_s[2] = {nullptr, nullptr};
+  int32_t *d_cand_i[2] = {nullptr, nullptr};
+  int64_t cand_cap = 0;
+  bool big_lds_set = false;
+};
+
+namespace {
+
+int waves_for(const bh_ctx *c) { return c->M <= 16384 ? 1 : 4; }
+
+size_t cross_lds_bytes(const bh_ctx *c, int waves, int tt) {
+  return (size_t)(4 * c->nwh + 2) * 8 + (size_t)16 * c->nw + (waves > 1 ? (size_t)waves * tt * 8 : 0);
+}
+
+template <int WAVES, int TT, int MODE>
+int launch_row(const bh_ctx *c, const bh::RowParams &p, size_t lds) {
+  auto kern = bh::row_kernel<WAVES, TT, MODE>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.n_rows), dim3(64 * WAVES), lds, c->stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "row_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+template <int WAVES, int MODE>
+int launch_row_tt(const bh_ctx *c, const bh::RowParams &p, int tt, size_t lds) {
+  switch (tt) {
+    case 0: return launch_row<WAVES, 0, MODE>(c, p, lds);
+    case 1: return launch_row<WAVES, 1, MODE>(c, p, lds);
+    case 2: return launch_row<WAVES, 2, MODE>(c, p, lds);
+    case 4: return launch_row<WAVES, 4, MODE>(c, p, lds);
+    default: return launch_row<WAVES, 8, MODE>(c, p, lds);
+  }
+}
+
+template <int MODE>
+int launch_row_mode(const bh_ctx *c, const bh::RowParams &p, int tt) {
+  const int waves = waves_for(c);
+  const size_t lds = MODE == bh::MODE_CROSS ? cross_lds_bytes(c, waves, tt)
+                                            : (waves > 1 ? (size_t)waves * tt * 8 : 0);
+  if (waves == 1) return launch_row_tt<1, MODE>(c, p, tt, lds);
+  return launch_row_tt<4, MODE>(c, p, tt, lds);
+}
+
+int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 ? 2 : tcount <= 4 ? 4 : 8; }
+
+bh::RowParams base_params(const bh_ctx *c) {
+  bh::RowParams p{};
+  p.thrA = c->d_thrA;
+  p.thrB = c->d_thrB;
+  p.eff = c->d_eff;
+  p.pitch = c->pitch;
+  p.effPitch = c->effPitch;
+  p.M = (int32_t)c->M;
+  p.half = c->half;
+  p.nwh = c->nwh;
+  p.nw = c->nw;
+  p.nvec = c->nvec;
+  p.T = (int32_t)c->T;
+  return p;
+}
+
+// GEBV of rows already in memory, for trait chunks [t_begin, T)
+int gebv_chunks(const bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
+  for (int t0 = t_begin; t0 < c->T; t0 += kMaxFusedTraits) {
+    bh::RowParams p = base_params(c);
+    p.src = d_pop;
+    p.gebv = d_gebv;
+    p.n_rows = (int32_t)rows;
+    p.t0 = t0;
+    p.tcount = (int32_t)std::min<int64_t>(kMaxFusedTraits, c->T - t0);
+    p.eff = c->d_eff + (int64_t)t0 * c->effPitch;
+    int rc = launch_row_mode<bh::MODE_GEBV>(c, p, tt_for(p.tcount));
+    if (rc) return rc;
+  }
+  return BH_OK;
+}
+
+int check_ctx(const bh_ctx *c) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+  return BH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bh_version(void) { return "breedhip 0.1.0 (gfx950)"; }
+const char *bh_last_error(void) { return g_err; }
+
+int bh_device_count(int *count) {
+  if (!count) return fail(BH_ERR_BAD_ARG, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(BH_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return BH_OK;
+}
+
+int64_t bh_max_markers(void) {
+  // LDS per cross ~= M/2 bytes (site words M/4 + interleaved masks M/4); 2^18 markers = 128 KiB
+  return (int64_t)1 << 18;
+}
+
+int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *recomb_vec,
+              const float *effects, bh_ctx **out) {
+  if (!out) return fail(BH_ERR_BAD_ARG, "null out");
+  *out = nullptr;
+  if (n_markers <= 0 || n_traits < 0 || !recomb_vec || (n_traits > 0 && !effects))
+    return fail(BH_ERR_BAD_ARG, "bh_create: need n_markers > 0, n_traits >= 0 and non-null arrays");
+  if (n_markers > bh_max_markers())
+    return fail(BH_ERR_UNSUPPORTED, "bh_create: %lld markers exceed the LDS-staged limit of %lld",
+                (long long)n_markers, (long long)bh_max_markers());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BH_ERR_NO_DEVICE, "no HIP device visible (libbreedhip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(BH_ERR_BAD_ARG, "device %d out of range [0,%d)", device, ndev);
+  BH_HIP(hipSetDevice(device));
+
+  bh_ctx *c = new (std::nothrow) bh_ctx();
+  if (!c) return fail(BH_ERR_OOM, "host allocation failed");
+  c->device = device;
+  c->M = n_markers;
+  c->T = n_traits;
+  c->pitch = round_up(2 * n_markers, 16);
+  c->half = (int32_t)((n_markers + 1) / 2);
+  c->nwh = (c->half + 63) / 64;
+  c->nw = (int32_t)((n_markers + 63) / 64);
+  c->nvec = (int32_t)(c->pitch / 16);
+  c->effPitch = (int64_t)c->nvec * 8;
+
+  const int64_t nthr = (int64_t)c->nwh * 64;
+  std::vector<uint32_t> thrA(nthr, 0u), thrB(nthr, 0u);
+  for (int64_t j = 0; j < c->half; ++j) {
+    thrA[j] = bh::threshold23(recomb_vec[j]);
+    if (j + c->half < n_markers) thrB[j] = bh::threshold23(recomb_vec[j + c->half]);
+  }
+  std::vector<double> eff((size_t)std::max<int64_t>(1, n_traits * c->effPitch), 0.0);
+  for (int64_t t = 0; t < n_traits; ++t)
+    for (int64_t m = 0; m < n_markers; ++m) eff[t * c->effPitch + m] = (double)effects[m * n_traits + t];
+
+  auto cleanup = [&](int rc) {
+    bh_destroy(c);
+    return rc;
+  };
+#define BH_HIP_C(call)                                                                          \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return cleanup(fail(e_ == hipErrorOutOfMemory ? BH_ERR_OOM : BH_ERR_HIP, "%s failed: %s", \
+                          #call, hipGetErrorString(e_)));                                       \
+  } while (0)
+  BH_HIP_C(hipMalloc(&c->d_thrA, nthr * sizeof(uint32_t)));
+  BH_HIP_C(hipMalloc(&c->d_thrB, nthr * sizeof(uint32_t)));
+  BH_HIP_C(hipMalloc(&c->d_eff, eff.size() * sizeof(double)));
+  BH_HIP_C(hipMemcpy(c->d_thrA, thrA.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
+  BH_HIP_C(hipMemcpy(c->d_thrB, thrB.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
+  BH_HIP_C(hipMemcpy(c->d_eff, eff.data(), eff.size() * sizeof(double), hipMemcpyHostToDevice));
+#undef BH_HIP_C
+  *out = c;
+  return BH_OK;
+}
+
+int bh_destroy(bh_ctx *c) {
+  if (!c) return BH_OK;
+  (void)hipSetDevice(c->device);
+  if (c->d_thrA) (void)hipFree(c->d_thrA);
+  if (c->d_thrB) (void)hipFree(c->d_thrB);
+  if (c->d_eff) (void)hipFree(c->d_eff);
+  for (int i = 0; i < 2; ++i) {
+    if (c->d_cand_s[i]) (void)hipFree(c->d_cand_s[i]);
+    if (c->d_cand_i[i]) (void)hipFree(c->d_cand_i[i]);
+  }
+  delete c;
+  return BH_OK;
+}
+
+int bh_set_stream(bh_ctx *c, void *hip_stream) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return BH_OK;
+}
+
+int bh_sync(bh_ctx *c) {
+  if (int rc = check_ctx(c)) return rc;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
+int64_t bh_row_pitch(const bh_ctx *c) { return c ? c->pitch : 0; }
+int64_t bh_n_markers(const bh_ctx *c) { return c ? c->M : 0; }
+int64_t bh_n_traits(const bh_ctx *c) { return c ? c->T : 0; }
+
+int bh_alloc(bh_ctx *c, int64_t bytes, void **dptr) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!dptr || bytes < 0) return fail(BH_ERR_BAD_ARG, "bh_alloc: bad arguments");
+  *dptr = nullptr;
+  BH_HIP(hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
+  return BH_OK;
+}
+
+int bh_free(bh_ctx *c, void *dptr) {
+  if (int rc = check_ctx(c)) return rc;
+  if (dptr) BH_HIP(hipFree(dptr));
+  return BH_OK;
+}
+
+int bh_memcpy_h2d(bh_ctx *c, void *dst, const void *src, int64_t bytes) {
+  if (int rc = check_ctx(c)) return rc;
+  if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(BH_ERR_BAD_ARG, "bh_memcpy_h2d: bad arguments");
+  if (bytes) BH_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  return BH_OK;
+}
+
+int bh_memcpy_d2h(bh_ctx *c, void *dst, const void *src, int64_t bytes) {
+  if (int rc = check_ctx(c)) return rc;
+  if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(BH_ERR_BAD_ARG, "bh_memcpy_d2h: bad arguments");
+  if (bytes) BH_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
+int bh_upload_population(bh_ctx *c, const uint8_t *host, int64_t rows, uint8_t *d_dst, int validate) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0 || (rows > 0 && (!host || !d_dst))) return fail(BH_ERR_BAD_ARG, "bh_upload_population: bad arguments");
+  if (rows == 0) return BH_OK;
+  const int64_t w = 2 * c->M;
+  if (validate) {
+    const int64_t n = rows * w;
+    uint8_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) bad |= host[i];
+    if (bad & 0xFE) return fail(BH_ERR_BAD_GENOTYPE, "genotype bytes must be 0 or 1");
+  }
+  if (c->pitch != w) BH_HIP(hipMemsetAsync(d_dst, 0, (size_t)(rows * c->pitch), c->stream));
+  BH_HIP(hipMemcpy2DAsync(d_dst, (size_t)c->pitch, host, (size_t)w, (size_t)w, (size_t)rows,
+                          hipMemcpyHostToDevice, c->stream));
+  BH_HIP(hipStreamSynchronize(c->stream));  // the host buffer may be pageable and short-lived
+  return BH_OK;
+}
+
+int bh_download_population(bh_ctx *c, const uint8_t *d_src, int64_t rows, uint8_t *host) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0 || (rows > 0 && (!host || !d_src))) return fail(BH_ERR_BAD_ARG, "bh_download_population: bad arguments");
+  if (rows == 0) return BH_OK;
+  const int64_t w = 2 * c->M;
+  BH_HIP(hipMemcpy2DAsync(host, (size_t)w, d_src, (size_t)c->pitch, (size_t)w, (size_t)rows,
+                          hipMemcpyDeviceToHost, c->stream));
+  BH_HIP(hipStreamSynchronize(c->stream));
+  return BH_OK;
+}
+
+int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
+             int64_t n_out, uint32_t sim_key[2], int rng_mode, uint8_t *d_out, float *d_gebv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!sim_key) return fail(BH_ERR_BAD_ARG, "bh_cross: null sim_key");
+  if (n_envs < 0 || n_out < 0 || pool_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_cross: negative size");
+  if (rng_mode != BH_RNG_SHARED_ENVS && rng_mode != BH_RNG_INDEPENDENT)
+    return fail(BH_ERR_BAD_ARG, "bh_cross: unknown rng_mode %d", rng_mode);
+  const int64_t rows = n_envs * n_out;
+  const int64_t B = rng_mode == BH_RNG_SHARED_ENVS ? n_out : rows;
+  if (rows > 0x3FFFFFFF || n_envs * pool_rows > 0x7FFFFFFF || 2 * (2 * B + 1) > 0xFFFFFFFFll)
+    return fail(BH_ERR_UNSUPPORTED, "bh_cross: too many rows for 32-bit indexing");
+  if (rows > 0) {
+    if (!d_pool || !d_idx || !d_out) return fail(BH_ERR_BAD_ARG, "bh_cross: null device pointer");
+    if (pool_rows == 0) return fail(BH_ERR_BAD_ARG, "bh_cross: empty parent pool");
+    if (d_gebv && c->T == 0) return fail(BH_ERR_BAD_ARG, "bh_cross: GEBV requested but the context has no traits");
+    const uint8_t *pool_end = d_pool + n_envs * pool_rows * c->pitch;
+    const uint8_t *out_end = d_out + rows * c->pitch;
+    if (d_out < pool_end && d_pool < out_end) return fail(BH_ERR_BAD_ARG, "bh_cross: d_out aliases d_pool");
+
+    bh::RowParams p = base_params(c);
+    p.src = d_pool;
+    p.out = d_out;
+    p.idx = d_idx;
+    p.gebv = d_gebv;
+    p.n_pool = (int32_t)pool_rows;
+    p.n_out = (int32_t)n_out;
+    p.n_rows = (int32_t)rows;
+    p.key0 = sim_key[0];
+    p.key1 = sim_key[1];
+    p.nkeys = (uint32_t)(2 * B + 1);
+    p.rng_shared = rng_mode == BH_RNG_SHARED_ENVS;
+    const bool fused = d_gebv && c->T <= kMaxFusedTraits;
+    p.t0 = 0;
+    p.tcount = fused ? (int32_t)c->T : 0;
+    if (int rc = launch_row_mode<bh::MODE_CROSS>(c, p, tt_for(p.tcount))) return rc;
+    if (d_gebv && !fused)
+      if (int rc = gebv_chunks(c, d_out, rows, d_gebv, 0)) return rc;
+  }
+  // Simulator.cross: keys = split(key, 2B+1); key <- keys[0]
+  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)(2 * B + 1), 0u);
+  sim_key[0] = nk.x;
+  sim_key[1] = nk.y;
+  return BH_OK;
+}
+
+int bh_gather(bh_ctx *c, const uint8_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
+              uint8_t *d_out, float *d_gebv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0 || src_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gather: negative size");
+  if (n_rows == 0) return BH_OK;
+  if (!d_src || !d_idx || !d_out) return fail(BH_ERR_BAD_ARG, "bh_gather: null device pointer");
+  if (src_rows == 0) return fail(BH_ERR_BAD_ARG, "bh_gather: empty source");
+  if (n_rows > 0x3FFFFFFF || src_rows > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_gather: too many rows");
+  if (d_gebv && c->T == 0) return fail(BH_ERR_BAD_ARG, "bh_gather: GEBV requested but the context has no traits");
+  bh::RowParams p = base_params(c);
+  p.src = d_src;
+  p.out = d_out;
+  p.idx = d_idx;
+  p.gebv = d_gebv;
+  p.n_pool = (int32_t)src_rows;
+  p.n_rows = (int32_t)n_rows;
+  const bool fused = d_gebv && c->T <= kMaxFusedTraits;
+  p.t0 = 0;
+  p.tcount = fused ? (int32_t)c->T : 0;
+  if (int rc = launch_row_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;
+  if (d_gebv && !fused) return gebv_chunks(c, d_out, n_rows, d_gebv, 0);
+  return BH_OK;
+}
+
+int bh_gebv(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gebv: negative size");
+  if (rows == 0 || c->T == 0) return BH_OK;
+  if (!d_pop || !d_gebv) return fail(BH_ERR_BAD_ARG, "bh_gebv: null device pointer");
+  if (rows > 0x3FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_gebv: too many rows");
+  return gebv_chunks(c, d_pop, rows, d_gebv, 0);
+}
+
+int bh_reward_max(bh_ctx *c, const float *d_gebv, int64_t n_envs, int64_t per_env, float *d_reward) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_envs < 0 || per_env < 0) return fail(BH_ERR_BAD_ARG, "bh_reward_max: negative size");
+  if (n_envs == 0) return BH_OK;
+  if (!d_gebv || !d_reward) return fail(BH_ERR_BAD_ARG, "bh_reward_max: null device pointer");
+  hipLaunchKernelGGL(bh::reward_max_kernel, dim3((unsigned)n_envs), dim3(256), 0, c->stream, d_gebv, per_env,
+                     d_reward);
+  BH_HIP(hipGetLastError());
+  return BH_OK;
+}
+
+int bh_topk(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t k, int32_t *d_idx_out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0 || n < 0 || k < 0 || k > n) return fail(BH_ERR_BAD_ARG, "bh_topk: need 0 <= k <= n");
+  if (n_rows == 0 || k == 0) return BH_OK;
+  if (!d_scores || !d_idx_out) return fail(BH_ERR_BAD_ARG, "bh_topk: null device pointer");
+  if (n > 0x7FFFFFFF || n_rows > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_topk: shape too large");
+  if (k > kTopkChunk) return fail(BH_ERR_UNSUPPORTED, "bh_topk: k > %d not supported", kTopkChunk);
+
+  if (!c->big_lds_set) {
+    BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::topk_chunk_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
+    c->big_lds_set = true;
+  }
+  // level 0 reads the caller's scores; every level keeps the best kk of each chunk of <= 16384
+  // candidates, until one chunk is left.  top-k of a union = top-k of the parts' top-k.
+  const float *in_s = d_scores;
+  const int32_t *in_i = nullptr;
+  int64_t n_in = n;
+  int flip = 0;
+  for (;;) {
+    const int64_t chunks = (n_in + kTopkChunk - 1) / kTopkChunk;
+    const int64_t chunk = chunks == 1 ? n_in : kTopkChunk;
+    const int64_t kk = std::min<int64_t>(k, chunk);
+    int64_t P = 2;
+    while (P < chunk) P <<= 1;
+    bh::TopkParams p{};
+    p.scores = in_s;
+    p.in_idx = in_i;
+    p.n_in = (int32_t)n_in;
+    p.chunk = (int32_t)chunk;
+    p.P = (int32_t)P;
+    p.kk = (int32_t)kk;
+    if (chunks == 1) {
+      p.out_idx = d_idx_out;
+      p.out_scores = nullptr;
+    } else {
+      const int64_t need = n_rows * chunks * kk;
+      if (need > c->cand_cap) {
+        for (int i = 0; i < 2; ++i) {
+          if (c->d_cand_s[i]) (void)hipFree(c->d_cand_s[i]);
+          if (c->d_cand_i[i]) (void)hipFree(c->d_cand_i[i]);
+          c->d_cand_s[i] = nullptr;
+          c->d_cand_i[i] = nullptr;
+        }
+        c->cand_cap = 0;
+        for (int i = 0; i < 2; ++i) {
+          BH_HIP(hipMalloc(&c->d_cand_s[i], need * sizeof(float)));
+          BH_HIP(hipMalloc(&c->d_cand_i[i], need * sizeof(int32_t)));
+        }
+        c->cand_cap = need;
+      }
+      p.out_idx = c->d_cand_i[flip];
+      p.out_scores = c->d_cand_s[flip];
+    }
+    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, P / 2));
+    hipLaunchKernelGGL(bh::topk_chunk_kernel, dim3((unsigned)chunks, (unsigned)n_rows), dim3(threads),
+                       (size_t)P * 8, c->stream, p);
+    BH_HIP(hipGetLastError());
+    if (chunks == 1) break;
+    in_s = c->d_cand_s[flip];
+    in_i = c->d_cand_i[flip];
+    n_in = chunks * kk;
+    flip ^= 1;
+  }
+  return BH_OK;
+}
+
+void bh_key_from_seed(uint64_t seed, uint32_t key[2]) {
+  key[0] = 0u;  // jax with x64 disabled drops the high word
+  key[1] = (uint32_t)(seed & 0xFFFFFFFFull);
+}
+
+int bh_key_split(const uint32_t key[2], int64_t num, uint32_t *out) {
+  if (!key || !out || num < 0 || num > 0x7FFFFFFF) return fail(BH_ERR_BAD_ARG, "bh_key_split: bad arguments");
+  for (int64_t k = 0; k < num; ++k) {
+    const bh::u32x2 s = bh::split_at(key[0], key[1], (uint32_t)num, (uint32_t)k);
+    out[2 * k] = s.x;
+    out[2 * k + 1] = s.y;
+  }
+  return BH_OK;
+}
+
+int bh_permutation(const uint32_t key_in[2], int64_t n, int32_t *out) {
+  if (!key_in || n < 0 || (n > 0 && !out) || n > 0x7FFFFFFF) return fail(BH_ERR_BAD_ARG, "bh_permutation: bad arguments");
+  // jax `_shuffle`: ceil(3 ln n / ln(2^32 - 1)) rounds of a stable sort by fresh random words
+  uint32_t key[2] = {key_in[0], key_in[1]};
+  const int rounds = (int)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n)) / std::log(4294967295.0));
+  std::vector<int32_t> x((size_t)n), y((size_t)n);
+  std::vector<uint32_t> bits((size_t)n);
+  std::vector<int32_t> order((size_t)n);
+  std::iota(x.begin(), x.end(), 0);
+  const int64_t L = n + (n & 1), h = L / 2;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const bh::u32x2 nk = bh::split_at(key[0], key[1], 2u, 0u), sub = bh::split_at(key[0], key[1], 2u, 1u);
+    key[0] = nk.x;
+    key[1] = nk.y;
+    for (int64_t i = 0; i < h; ++i) {  // random_bits(sub, n): odd n is padded with a 0 counter
+      const uint32_t c1 = (i + h < n) ? (uint32_t)(i + h) : 0u;
+      const bh::u32x2 o = bh::threefry2x32(sub.x, sub.y, (uint32_t)i, c1);
+      bits[(size_t)i] = o.x;
+      if (i + h < n) bits[(size_t)(i + h)] = o.y;
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return bits[(size_t)a] < bits[(size_t)b]; });
+    for (int64_t i = 0; i < n; ++i) y[(size_t)i] = x[(size_t)order[(size_t)i]];
+    x.swap(y);
+  }
+  std::copy(x.begin(), x.end(), out);
+  return BH_OK;
+}
+
+int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n, int32_t *out) {
+  if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !out))
+    return fail(BH_ERR_BAD_ARG, "bh_founders: need 0 <= n <= n_germplasm");
+  std::vector<uint32_t> keys((size_t)(2 * (n_envs + 1)));
+  if (int rc = bh_key_split(env_key, n_envs + 1, keys.data())) return rc;
+  std::vector<int32_t> perm((size_t)n_germplasm);
+  for (int64_t e = 0; e < n_envs; ++e) {
+    if (int rc = bh_permutation(&keys[(size_t)(2 * (e + 1))], n_germplasm, perm.data())) return rc;
+    std::copy(perm.begin(), perm.begin() + n, out + e * n);
+  }
+  env_key[0] = keys[0];
+  env_key[1] = keys[1];
+  return BH_OK;
+}
+
+}  // extern "C"

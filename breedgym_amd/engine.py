@@ -1,0 +1,206 @@
+"""The device engine: genotype rows in HBM and the HIP operators that act on them.
+
+``HipEngine`` is a thin Python face of one ``bh_ctx`` (include/breedhip.h).  torch is used for
+what it is good at here -- owning device memory and the stream -- and nothing else: every
+operator is a hand-written HIP kernel behind the C ABI, called with raw device pointers.
+
+Layout: a population is a ``(rows, pitch)`` uint8 tensor, ``pitch = 2*M`` rounded up to 16
+bytes; bytes ``[2m, 2m+1]`` of a row are the two alleles of marker ``m`` (the reference's
+``(N, M, 2)`` bool layout, one byte per allele).  ``as_genotypes`` gives the zero-copy
+``(rows, M, 2)`` bool view.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class DeviceArray(torch.Tensor):
+    """A torch.Tensor that converts to NumPy implicitly, the way a ``jax.Array`` does.
+
+    The reference hands JAX arrays to user code that feeds them straight to NumPy
+    (``np.max(infos["GEBV"], axis=(1, 2))``, vec_env.py:97; ``np.add.outer`` in
+    tests/test_vec.py:198).  A plain CUDA tensor refuses that; this subclass copies to host
+    on ``__array__`` instead.  Everything else is ordinary torch.
+    """
+
+    @staticmethod
+    def wrap(t: torch.Tensor) -> "DeviceArray":
+        return t.as_subclass(DeviceArray)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.detach().as_subclass(torch.Tensor).cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def block_until_ready(self):
+        if self.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+        return self
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class EngineBase:
+    """Row layout and memory helpers shared by every engine; operators are abstract.
+
+    Attributes an engine provides: ``device``, ``n_markers``, ``n_traits``, ``pitch``."""
+
+    # ---- memory ------------------------------------------------------------------------
+    def empty_population(self, rows: int) -> torch.Tensor:
+        return torch.empty((int(rows), self.pitch), dtype=torch.uint8, device=self.device)
+
+    def empty(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def as_genotypes(self, rows_t: torch.Tensor, *lead) -> DeviceArray:
+        """(rows, pitch) uint8 -> zero-copy (*lead, M, 2) bool view."""
+        rows = rows_t.shape[0]
+        if not lead:
+            lead = (rows,)
+        g = rows_t[:, : 2 * self.n_markers].view(torch.bool)
+        strides, acc = [], self.pitch
+        for d in reversed(lead):
+            strides.append(acc)
+            acc *= d
+        strides = tuple(reversed(strides))
+        return DeviceArray.wrap(g.as_strided((*lead, self.n_markers, 2), (*strides, 2, 1)))
+
+    def upload_population(self, pop, validate: bool = True) -> torch.Tensor:
+        """host (rows, M, 2) bool/uint8 (or an already resident (rows, pitch) tensor) -> device rows."""
+        if isinstance(pop, torch.Tensor):
+            pop = pop.as_subclass(torch.Tensor)
+            if pop.device == self.device:
+                if pop.dtype == torch.uint8 and pop.dim() == 2 and pop.shape[1] == self.pitch:
+                    return pop
+                return self.pack_device(pop)
+            pop = pop.cpu().numpy()
+        a = np.asarray(pop)
+        if a.ndim != 3 or a.shape[1] != self.n_markers or a.shape[2] != 2:
+            raise ValueError(f"population must have shape (n, {self.n_markers}, 2), got {a.shape}")
+        a = np.ascontiguousarray(a.view(np.uint8) if a.dtype == np.bool_ else a.astype(np.uint8))
+        return self._upload_rows(a, validate)
+
+    def _upload_rows(self, a: np.ndarray, validate: bool) -> torch.Tensor:
+        raise NotImplementedError
+
+    def pack_device(self, g: torch.Tensor) -> torch.Tensor:
+        """device (rows, M, 2) bool/uint8 tensor -> (rows, pitch) rows (a device-side copy)."""
+        g = g.reshape(-1, 2 * self.n_markers)
+        g = g.view(torch.uint8) if g.dtype == torch.bool else g.to(torch.uint8)
+        if self.pitch == 2 * self.n_markers:
+            return g.contiguous()
+        out = torch.zeros((g.shape[0], self.pitch), dtype=torch.uint8, device=self.device)
+        out[:, : 2 * self.n_markers] = g
+        return out
+
+    def download_population(self, rows_t: torch.Tensor) -> np.ndarray:
+        raise NotImplementedError
+
+    def to_device(self, a, dtype) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+
+class HipEngine(EngineBase):
+    """One GPU, one genetic map: thresholds and marker effects resident in HBM."""
+
+    def __init__(self, recombination_vec: np.ndarray, marker_effects: np.ndarray, device=None):
+        L = _lib.lib()
+        if not torch.cuda.is_available() or _lib.device_count() == 0:
+            raise RuntimeError(
+                "breedgym_amd needs an AMD GPU (gfx950): no HIP device is visible and there is no CPU fallback"
+            )
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        r = np.ascontiguousarray(recombination_vec, np.float32)
+        eff = np.ascontiguousarray(marker_effects, np.float32)
+        if eff.ndim == 1:
+            eff = eff[:, None]
+        if r.ndim != 1 or eff.shape[0] != r.shape[0]:
+            raise ValueError("recombination_vec must be (M,) and marker_effects (M, T)")
+        self.n_markers, self.n_traits = int(eff.shape[0]), int(eff.shape[1])
+        h = ctypes.c_void_p()
+        _lib.check(
+            L.bh_create(
+                self.device.index, self.n_markers, self.n_traits,
+                r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                eff.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(h),
+            )
+        )
+        self._h = h
+        self._L = L
+        self.pitch = int(L.bh_row_pitch(h))
+        # torch's default stream is the null stream, which is also the context's default
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory ------------------------------------------------------------------------
+    def _upload_rows(self, a: np.ndarray, validate: bool) -> torch.Tensor:
+        out = self.empty_population(a.shape[0])
+        _lib.check(self._L.bh_upload_population(self._h, a.ctypes.data, a.shape[0], out.data_ptr(), int(validate)))
+        return out
+
+    def download_population(self, rows_t: torch.Tensor) -> np.ndarray:
+        rows = rows_t.shape[0]
+        out = np.empty((rows, self.n_markers, 2), np.uint8)
+        _lib.check(self._L.bh_download_population(self._h, rows_t.data_ptr(), rows, out.ctypes.data))
+        return out.view(np.bool_)
+
+    # ---- operators ---------------------------------------------------------------------
+    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None) -> None:
+        """Fused gather + meiosis + GEBV (bh_cross).  ``key`` (uint32[2]) is advanced in place."""
+        assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_envs * n_out * 2
+        assert pool.shape[0] >= n_envs * pool_rows and out.shape[0] >= n_envs * n_out
+        assert gebv is None or (gebv.dtype == torch.float32 and gebv.numel() >= n_envs * n_out * self.n_traits)
+        _lib.check(
+            self._L.bh_cross(
+                self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
+                key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out.data_ptr(), _ptr(gebv),
+            )
+        )
+
+    def gather(self, src, idx, out, gebv=None) -> None:
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and out.shape[0] >= idx.numel()
+        _lib.check(
+            self._L.bh_gather(self._h, src.data_ptr(), src.shape[0], idx.data_ptr(), idx.numel(), out.data_ptr(), _ptr(gebv))
+        )
+
+    def gebv(self, pop, out=None) -> torch.Tensor:
+        rows = pop.shape[0]
+        if out is None:
+            out = torch.empty((rows, self.n_traits), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.bh_gebv(self._h, pop.data_ptr(), rows, out.data_ptr()))
+        return out
+
+    def reward_max(self, gebv, n_envs, out=None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((n_envs,), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.bh_reward_max(self._h, gebv.data_ptr(), n_envs, gebv.numel() // max(n_envs, 1), out.data_ptr()))
+        return out
+
+    def topk(self, scores, k) -> torch.Tensor:
+        s = scores.to(device=self.device, dtype=torch.float32).contiguous()
+        s2 = s.reshape(-1, s.shape[-1])
+        out = torch.empty((s2.shape[0], int(k)), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.bh_topk(self._h, s2.data_ptr(), s2.shape[0], s2.shape[1], int(k), out.data_ptr()))
+        return out.reshape(*s.shape[:-1], int(k))
+
+    def sync(self) -> None:
+        _lib.check(self._L.bh_sync(self._h))

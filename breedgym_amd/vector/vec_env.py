@@ -1,0 +1,201 @@
+"""``VecBreedGym``: E independent breeding programmes stepped as one fused GPU launch.
+
+Drop-in for ``breedgym.vector.vec_env.VecBreedGym`` (reference ``vec_env.py:30-137``): same
+constructor keywords, same ``reset``/``step`` contract, same attributes the wrappers reach
+through (``simulator``, ``individual_per_gen``, ``random_key``, ``populations``, ``germplasm``,
+``device``, ``step_idx`` ...).  What changes is underneath: ``step`` is one HIP kernel that
+gathers the parents through ``actions``, runs meiosis, writes the offspring and accumulates
+their GEBV -- ``populations[arange, actions]`` (vec_env.py:89-90) is never materialised and the
+GEBV pass (vec_env.py:132-134) never re-reads the offspring.
+
+Differences a caller can see, all opt-in or benign:
+  * arrays are ``DeviceArray`` (a torch.Tensor on the GPU that converts to NumPy implicitly,
+    like the reference's jax.Array); observations are bool views of the resident rows;
+  * ``env_rng="independent"`` gives every env its own crossover randomness; the default
+    ``"shared"`` reproduces the reference, whose ``jax.vmap`` over an un-batched simulator key
+    (vec_env.py:75-77) hands all envs the same gamete keys;
+  * ``sync_rewards=False`` returns the reward vector as a device array and so never blocks.
+"""
+from pathlib import Path
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import _lib, rng, spaces
+from ..engine import DeviceArray
+from ..simulator import Simulator
+from ..utils.paths import DATA_PATH
+
+GENOME_FILE = DATA_PATH.joinpath("small_geno.npy")  # the reference's default (vec_env.py:19)
+
+try:  # a genuine gymnasium VectorEnv when gymnasium is there
+    from gymnasium.experimental.vector import VectorEnv as _VectorEnvBase
+except ImportError:
+    try:
+        from gymnasium.vector import VectorEnv as _VectorEnvBase
+    except ImportError:
+        _VectorEnvBase = object
+
+
+class VecBreedGym(_VectorEnvBase):
+    def __init__(
+        self,
+        num_envs: int = 1,
+        initial_population: Union[str, Path, np.ndarray, torch.Tensor] = GENOME_FILE,
+        individual_per_gen: Optional[int] = None,
+        num_generations: int = 10,
+        autoreset: bool = True,
+        reward_shaping: bool = False,
+        env_rng: str = "shared",
+        sync_rewards: bool = True,
+        **kwargs,
+    ):
+        if env_rng not in ("shared", "independent"):
+            raise ValueError("env_rng must be 'shared' or 'independent'")
+        self.num_envs = num_envs
+        self.num_generations = num_generations
+        self.autoreset = autoreset
+        self.reward_shaping = reward_shaping
+        self.sync_rewards = sync_rewards
+        self._rng_mode = _lib.RNG_SHARED_ENVS if env_rng == "shared" else _lib.RNG_INDEPENDENT
+        self.simulator = Simulator(**kwargs)
+        self.device = self.simulator.device
+
+        if isinstance(initial_population, (str, Path)):
+            germplasm = self.simulator.load_population(initial_population)
+        else:
+            germplasm = self.simulator.device_put(initial_population)
+        self.germplasm = germplasm
+        self._germ_rows, _ = self.simulator._rows_of(germplasm)
+        if individual_per_gen is None:
+            individual_per_gen = len(self.germplasm)
+        self.individual_per_gen = individual_per_gen
+
+        self.observation_space = spaces.Box(
+            low=0, high=1,
+            shape=(self.num_envs, self.individual_per_gen, self.germplasm.shape[1], 2), dtype=np.int8,
+        )
+        self.action_space = spaces.Box(
+            low=0, high=self.individual_per_gen,
+            shape=(self.num_envs, self.individual_per_gen, 2), dtype=np.int32,
+        )
+
+        self._populations = None
+        self._rows = None  # (E * n, pitch) uint8 rows behind `populations`
+        self._n = None
+        self.step_idx = None
+        self.reset_infos = {}
+        self.random_key = None
+
+    # ---- helpers -----------------------------------------------------------------------------
+    @property
+    def populations(self):
+        return self._populations
+
+    @populations.setter
+    def populations(self, value):
+        # wrappers assign fresh populations (breeding_programs_env.py:56): adopt their rows
+        if value is None:
+            self._populations, self._rows, self._n = None, None, None
+            return
+        rows, lead = self.simulator._rows_of(value)
+        if len(lead) != 2 or lead[0] != self.num_envs:
+            raise ValueError(f"populations must have shape ({self.num_envs}, n, M, 2)")
+        self._rows, self._n = rows, lead[1]
+        self._populations = self.simulator.engine.as_genotypes(rows, *lead)
+
+    def _adopt(self, rows, n):
+        self._rows, self._n = rows, n
+        self._populations = self.simulator.engine.as_genotypes(rows, self.num_envs, n)
+
+    def _device_actions(self, actions) -> torch.Tensor:
+        eng = self.simulator.engine
+        if isinstance(actions, torch.Tensor):
+            a = actions.as_subclass(torch.Tensor)
+            if a.device != eng.device or a.dtype != torch.int32 or not a.is_contiguous():
+                a = a.to(device=eng.device, dtype=torch.int32).contiguous()
+        else:
+            a = np.asarray(actions)
+            if a.dtype != np.int32:
+                a = a.astype(np.int32)
+            a = torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+        if a.dim() != 3 or a.shape[0] != self.num_envs or a.shape[2] != 2:
+            raise ValueError(f"actions must have shape ({self.num_envs}, n, 2), got {tuple(a.shape)}")
+        return a
+
+    def cross(self, parents):
+        """``vmap(simulator.cross)`` on materialised parents (E, n, 2, M, 2) (vec_env.py:75-77)."""
+        E, n = parents.shape[:2]
+        M = self.simulator.n_markers
+        pool, _ = self.simulator._rows_of(parents.reshape(E * n * 2, M, 2))
+        eng = self.simulator.engine
+        idx = torch.arange(2 * n, dtype=torch.int32, device=eng.device).reshape(1, n, 2).repeat(E, 1, 1).contiguous()
+        out = eng.empty_population(E * n)
+        self.simulator.cross_indexed(pool, E, 2 * n, idx, n, out, None, self._rng_mode)
+        return eng.as_genotypes(out, E, n)
+
+    def _rewards(self, gebv: torch.Tensor):
+        r = self.simulator.engine.reward_max(gebv, self.num_envs)
+        if self.sync_rewards:
+            return r.cpu().numpy()  # the reference's np.max(...) also syncs here (vec_env.py:97-98)
+        return DeviceArray.wrap(r)
+
+    # ---- gymnasium surface -------------------------------------------------------------------
+    def step(self, actions) -> Tuple[DeviceArray, np.ndarray, np.ndarray, np.ndarray, dict]:
+        if self._rows is None:
+            raise RuntimeError("call reset() before step()")
+        eng = self.simulator.engine
+        idx = self._device_actions(actions)
+        E, n_pool, n_out = self.num_envs, self._n, idx.shape[1]
+        out = eng.empty_population(E * n_out)
+        gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
+        self.simulator.cross_indexed(self._rows, E, n_pool, idx, n_out, out, gebv, self._rng_mode)
+        self._adopt(out, n_out)
+        self.step_idx += 1
+
+        infos = {"GEBV": DeviceArray.wrap(gebv)}
+        done = self.step_idx == self.num_generations
+        if self.reward_shaping or done:
+            rews = self._rewards(gebv)
+        else:
+            rews = np.zeros(self.num_envs)
+
+        if done and self.autoreset:
+            self.reset()  # like the reference: obs is post-reset, infos pre-reset (vec_env.py:102-107)
+
+        terminated = np.full(self.num_envs, False)
+        truncated = np.full(self.num_envs, done)
+        return self.populations, rews, terminated, truncated, infos
+
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None) -> Tuple[DeviceArray, dict]:
+        self.step_idx = 0
+        if seed is not None:
+            self.simulator.set_seed(seed)
+            self.random_key = rng.key(seed)
+        elif self.random_key is None:
+            seed = int(np.random.randint(2**32, dtype=np.uint64))
+            self.random_key = rng.key(seed)
+
+        if options is not None and "individual_per_gen" in options.keys():
+            self.individual_per_gen = options["individual_per_gen"]
+
+        eng = self.simulator.engine
+        E, n = self.num_envs, self.individual_per_gen
+        founders, self.random_key = rng.founders(self.random_key, E, len(self.germplasm), n)
+        idx = torch.from_numpy(founders.reshape(-1)).to(eng.device)
+        rows = eng.empty_population(E * n)
+        gebv = eng.empty((E, n, eng.n_traits), torch.float32)
+        eng.gather(self._germ_rows, idx, rows, gebv)
+        self._adopt(rows, n)
+        self.reset_infos = {"GEBV": DeviceArray.wrap(gebv)}
+        return self.populations, self.reset_infos
+
+    def get_info(self) -> dict:
+        return {"GEBV": self.simulator.GEBV_model(self.populations)}
+
+    def set_attr(self, name, values):
+        return setattr(self, name, values)
+
+    def close(self, **kwargs):
+        pass

@@ -1,0 +1,140 @@
+/*
+ * breedhip.h -- C ABI of libbreedhip.so, the MI355X (gfx950) implementation of the one
+ * data-parallel hot path of younik/breedgym: vectorised reset()/step() =
+ * parent gather -> meiosis/cross -> GEBV -> reward / top-k.
+ *
+ * The reference has no FFI of its own; its seam is the Python object
+ * `self.simulator` (a chromax.Simulator) called from
+ *     breedgym/vector/vec_env.py:45-50,77,114,133     (VecBreedGym)
+ *     breedgym/breedgym.py:36-38,117,143,233,240      (BreedGym)
+ * Every entry point below names the reference call it replaces.  Plain C types
+ * only: pointers, sizes, status codes.  Device pointers are raw HIP device
+ * addresses (e.g. torch.Tensor.data_ptr()); nothing here knows about torch.
+ *
+ * Conventions
+ *   - every function returns BH_OK (0) or a negative bh_status; the message of
+ *     the last failure on the calling thread is at bh_last_error().
+ *   - genotypes are 1 byte per allele in {0,1}, laid out (rows, M, 2) like the
+ *     reference's bool arrays, with a row pitch of bh_row_pitch() bytes
+ *     (= 2*M rounded up to 16; equal to 2*M, i.e. plain contiguous, when
+ *     M % 8 == 0).  Pad bytes are zero.
+ *   - all work is enqueued on the context's HIP stream (default: the null
+ *     stream, which is also torch's default stream) and is asynchronous;
+ *     bh_sync() or any stream sync makes results visible to the host.
+ *   - a context is bound to one device and is not re-entrant; use one per
+ *     thread / per process (one process per GPU is the intended deployment).
+ */
+#ifndef BREEDHIP_H
+#define BREEDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bh_status {
+  BH_OK = 0,
+  BH_ERR_BAD_ARG = -1,     /* null pointer, negative size, bad mode            */
+  BH_ERR_OOM = -2,         /* hipMalloc / host allocation failed               */
+  BH_ERR_HIP = -3,         /* any other HIP runtime error                      */
+  BH_ERR_UNSUPPORTED = -4, /* shape outside what the kernels handle            */
+  BH_ERR_NO_DEVICE = -5,   /* no gfx950 device visible                         */
+  BH_ERR_BAD_GENOTYPE = -6 /* a genotype byte other than 0/1                   */
+} bh_status;
+
+/* RNG stream assignment inside one bh_cross call (see DESIGN.md "RNG contract"). */
+typedef enum bh_rng_mode {
+  BH_RNG_SHARED_ENVS = 0, /* every env gets the same gamete keys: what jax.vmap over the
+                             un-batched simulator key does in vec_env.py:75-77       */
+  BH_RNG_INDEPENDENT = 1  /* the E*n crosses form one flat chromax cross() batch      */
+} bh_rng_mode;
+
+typedef struct bh_ctx bh_ctx; /* opaque */
+
+const char *bh_version(void);
+const char *bh_last_error(void);
+int bh_device_count(int *count);
+
+/* ---- context = the simulator's device-side constants -------------------------------
+ * Replaces `Simulator(genetic_map=..., trait_names=...)` + `.device`
+ * (vec_env.py:45-46, breedgym.py:36,40).  recomb_vec: (M) f32 host, the per-marker
+ * recombination probability r[m] (first marker of a chromosome already 0.5);
+ * effects: (M, T) f32 host, row-major, marker effects of the T selected traits. */
+int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *recomb_vec,
+              const float *effects, bh_ctx **out);
+int bh_destroy(bh_ctx *ctx);
+int bh_set_stream(bh_ctx *ctx, void *hip_stream);
+int bh_sync(bh_ctx *ctx);
+int64_t bh_row_pitch(const bh_ctx *ctx);
+int64_t bh_n_markers(const bh_ctx *ctx);
+int64_t bh_n_traits(const bh_ctx *ctx);
+/* largest marker count the LDS-staged crossover masks allow */
+int64_t bh_max_markers(void);
+
+/* ---- device memory for callers without a HIP runtime of their own ------------------ */
+int bh_alloc(bh_ctx *ctx, int64_t bytes, void **dptr);
+int bh_free(bh_ctx *ctx, void *dptr);
+int bh_memcpy_h2d(bh_ctx *ctx, void *dst, const void *src, int64_t bytes);
+int bh_memcpy_d2h(bh_ctx *ctx, void *dst, const void *src, int64_t bytes); /* synchronises */
+
+/* `simulator.load_population` / `jax.device_put(germplasm)` (vec_env.py:48-52):
+ * host (rows, M, 2) contiguous bytes -> device rows at bh_row_pitch().  With
+ * `validate` != 0 every byte must be 0 or 1 (BH_ERR_BAD_GENOTYPE otherwise). */
+int bh_upload_population(bh_ctx *ctx, const uint8_t *host, int64_t rows, uint8_t *d_dst,
+                         int validate);
+/* device rows -> host (rows, M, 2) contiguous; synchronises. */
+int bh_download_population(bh_ctx *ctx, const uint8_t *d_src, int64_t rows, uint8_t *host);
+
+/* ---- the hot path -------------------------------------------------------------------
+ * bh_cross = `populations[arange, actions]` + `vmap(simulator.cross)` + `GEBV_model`
+ * (vec_env.py:88-91,132-134; single env: breedgym.py:142-143,233) fused in one kernel:
+ * the parent gather is never materialised.
+ *   d_pool  (n_envs, pool_rows, pitch) u8   the current populations
+ *   d_idx   (n_envs, n_out, 2) int32        env-local parent rows; negative wraps once,
+ *                                           out of range is clamped (JAX gather rules)
+ *   d_out   (n_envs, n_out, pitch) u8       offspring; out[e,i,m,p] comes from parent p
+ *   d_gebv  (n_envs, n_out, T) f32 or NULL  GEBV of the offspring
+ *   sim_key host, in/out                    the simulator's threefry key; advanced once
+ *                                           per call like `Simulator.cross` does
+ * d_out must not alias d_pool. */
+int bh_cross(bh_ctx *ctx, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows,
+             const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
+             uint8_t *d_out, float *d_gebv);
+
+/* Row gather + GEBV: `_random_selection` / `germplasm[selected_indices]` + `get_info`
+ * (vec_env.py:22-27,126-129; breedgym.py:121-125).  d_idx (n_rows) int32 into d_src
+ * (src_rows, pitch); d_out (n_rows, pitch); d_gebv (n_rows, T) or NULL. */
+int bh_gather(bh_ctx *ctx, const uint8_t *d_src, int64_t src_rows, const int32_t *d_idx,
+              int64_t n_rows, uint8_t *d_out, float *d_gebv);
+
+/* `simulator.GEBV_model(population)` (vec_env.py:133): d_pop (rows, pitch) -> (rows, T) f32.
+ * GEBV[i,t] = sum_m (pop[i,m,0] + pop[i,m,1]) * effects[m,t], accumulated in f64. */
+int bh_gebv(bh_ctx *ctx, const uint8_t *d_pop, int64_t rows, float *d_gebv);
+
+/* `np.max(infos["GEBV"], axis=(1, 2))` (vec_env.py:97): (n_envs, per_env) f32 -> (n_envs) f32. */
+int bh_reward_max(bh_ctx *ctx, const float *d_gebv, int64_t n_envs, int64_t per_env,
+                  float *d_reward);
+
+/* `jax.lax.top_k(scores, k)[1]` (vec_wrappers.py:64; Simulator.select): for each of n_rows
+ * score vectors of length n, the indices of the k largest in descending order, ties to the
+ * lower index.  d_scores (n_rows, n) f32; d_idx_out (n_rows, k) int32. */
+int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64_t k,
+            int32_t *d_idx_out);
+
+/* ---- host-side RNG plumbing (JAX threefry key chains) -------------------------------- */
+/* jax.random.key(seed) (vec_env.py:115, Simulator.set_seed). */
+void bh_key_from_seed(uint64_t seed, uint32_t key[2]);
+/* jax.random.split(key, num) -> out (num, 2). */
+int bh_key_split(const uint32_t key[2], int64_t num, uint32_t *out);
+/* jax.random.permutation(key, n) -> out (n) int32. */
+int bh_permutation(const uint32_t key[2], int64_t n, int32_t *out);
+/* The founder draw of VecBreedGym.reset (vec_env.py:120-128): keys = split(env_key, E+1);
+ * env_key <- keys[0]; env e takes permutation(keys[1+e], N)[:n].  out (E, n) int32 host. */
+int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

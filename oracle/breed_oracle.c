@@ -179,6 +179,17 @@ void bo_topk(const float *scores, int64_t n, int64_t k, int32_t *out) {
 /* cross / GEBV / reward                                                    */
 /* ------------------------------------------------------------------------ */
 
+int64_t bo_norm_index(int64_t i, int64_t n) {
+  /* JAX/NumPy-style retrieval indexing as the reference's gather sees it
+   * (vec_env.py:89-90): negative indices count from the end, anything still
+   * out of range is clamped (the action space's `high` is inclusive:
+   * vec_env.py:63-68, so index n does occur). */
+  if (i < 0) i += n;
+  if (i < 0) i = 0;
+  if (i >= n) i = n - 1;
+  return i;
+}
+
 int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
              int64_t n_out, int64_t M, const float *r, uint32_t key[2],
              int rng_mode, uint8_t *out, uint8_t *masks) {
@@ -187,8 +198,7 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
    *   gamete (b, p) uses keys[1 + 2*b + p];
    *   inside meiosis: rec_key = split(gamete_key, 2)[0].
    * B = n_out when the key is shared by all envs, E*n_out otherwise. */
-  for (int64_t j = 0; j < E * n_out * 2; ++j)
-    if (idx[j] < 0 || idx[j] >= n_pool) return -1;
+  if (n_pool <= 0 && E * n_out > 0) return -1;
 
   int64_t B = rng_mode == 0 ? n_out : E * n_out;
   uint32_t *keys = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)(2 * B + 1));
@@ -208,7 +218,7 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
         uint32_t two[4];
         bo_split(&keys[2 * (1 + 2 * b + p)], 2, two);
         bo_meiosis_mask(two, r, M, mask); /* two[0..1] = rec key */
-        const uint8_t *par = pool + (e * n_pool + idx[2 * c + p]) * row;
+        const uint8_t *par = pool + (e * n_pool + bo_norm_index(idx[2 * c + p], n_pool)) * row;
         uint8_t *o = out + c * row;
         for (int64_t m = 0; m < M; ++m) o[2 * m + p] = par[2 * m + mask[m]];
         if (masks) memcpy(masks + (2 * c + p) * M, mask, (size_t)M);

@@ -75,7 +75,9 @@ void bo_meiosis_mask(const uint32_t rec_key[2], const float *r, int64_t M,
  *   rng_mode 0: every env sees the same keys (what jax.vmap over an
  *               un-batched simulator key does: vec_env.py:75-77)
  *            1: the E*n_out crosses are one flat chromax cross() batch
- * Returns 0, or -1 on an out-of-range parent index. */
+ * Parent indices follow JAX retrieval indexing: negative wraps once, then clamp.
+ * Returns 0, or -1 if a pool is empty. */
+int64_t bo_norm_index(int64_t i, int64_t n);
 int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
              int64_t n_out, int64_t M, const float *r, uint32_t key[2],
              int rng_mode, uint8_t *out, uint8_t *masks);

@@ -132,7 +132,7 @@ def cross(pool, idx, r, key, rng_mode: int = 0, return_masks: bool = False):
         _p(masks, _u8p) if return_masks else None,
     )
     if rc != 0:
-        raise IndexError("parent index out of range")
+        raise IndexError("empty parent pool")
     return (out, k, masks) if return_masks else (out, k)
 
 

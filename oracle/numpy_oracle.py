@@ -114,6 +114,10 @@ def vec_step_cross(populations, actions, r, sim_key, rng_mode=0):
     rng_mode 0 reproduces vmap over an un-batched simulator key: every env gets the
     same gamete keys.  rng_mode 1 treats the E*n crosses as one flat batch."""
     E, n = actions.shape[:2]
+    n_pool = populations.shape[1]
+    # JAX retrieval indexing: negatives wrap once, the rest is clamped (high is inclusive,
+    # vec_env.py:63-68, so index n_pool can occur)
+    actions = np.clip(np.where(actions < 0, actions + n_pool, actions), 0, n_pool - 1)
     parents = populations[np.arange(E)[:, None, None], actions]  # (E,n,2,M,2) materialised
     if rng_mode == 0:
         outs, newkey = [], None

@@ -1,0 +1,81 @@
+"""Test double: an engine whose operators are the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY.  It lets the CPU test-suite drive the *host logic* of the product
+(``Simulator``, ``VecBreedGym``, ``BreedGym``, the sharding driver) without a GPU, through the
+``engine=`` seam of ``Simulator``.  Nothing in ``breedgym_amd`` imports this.
+"""
+import numpy as np
+import torch
+
+from breedgym_amd.engine import EngineBase
+from oracle import c_oracle as co
+
+
+class OracleEngine(EngineBase):
+    def __init__(self, recombination_vec, marker_effects, device=None):
+        self.device = torch.device("cpu")
+        self.r = np.ascontiguousarray(recombination_vec, np.float32)
+        eff = np.ascontiguousarray(marker_effects, np.float32)
+        self.effects = eff if eff.ndim == 2 else eff[:, None]
+        self.n_markers, self.n_traits = self.effects.shape
+        self.pitch = (2 * self.n_markers + 15) // 16 * 16
+        self.calls = {"cross": 0, "gather": 0, "gebv": 0, "reward_max": 0, "topk": 0}
+
+    def _g(self, rows_t):  # (rows, pitch) -> (rows, M, 2) numpy u8
+        return rows_t.numpy()[:, : 2 * self.n_markers].reshape(-1, self.n_markers, 2)
+
+    def _upload_rows(self, a, validate):
+        if validate and a.max(initial=0) > 1:
+            raise ValueError("genotype bytes must be 0 or 1")
+        out = torch.zeros((a.shape[0], self.pitch), dtype=torch.uint8)
+        out[:, : 2 * self.n_markers] = torch.from_numpy(a.reshape(a.shape[0], -1))
+        return out
+
+    def download_population(self, rows_t):
+        return self._g(rows_t).copy().view(np.bool_)
+
+    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None):
+        self.calls["cross"] += 1
+        p = self._g(pool)[: n_envs * pool_rows].reshape(n_envs, pool_rows, self.n_markers, 2)
+        o, newkey = co.cross(p, idx.numpy().reshape(n_envs, n_out, 2), self.r, key, rng_mode)
+        key[:] = newkey
+        out[: n_envs * n_out] = 0
+        out[: n_envs * n_out, : 2 * self.n_markers] = torch.from_numpy(o.reshape(n_envs * n_out, -1))
+        if gebv is not None:
+            gebv.reshape(-1, self.n_traits)[: n_envs * n_out] = torch.from_numpy(
+                co.gebv(o.reshape(-1, self.n_markers, 2), self.effects))
+
+    def gather(self, src, idx, out, gebv=None):
+        self.calls["gather"] += 1
+        n = src.shape[0]
+        i = idx.numpy().astype(np.int64).reshape(-1)
+        i = np.clip(np.where(i < 0, i + n, i), 0, n - 1)
+        out[: len(i)] = src[torch.from_numpy(i)]
+        if gebv is not None:
+            gebv.reshape(-1, self.n_traits)[: len(i)] = torch.from_numpy(co.gebv(self._g(out[: len(i)]), self.effects))
+
+    def gebv(self, pop, out=None):
+        self.calls["gebv"] += 1
+        g = torch.from_numpy(co.gebv(self._g(pop), self.effects))
+        if out is not None:
+            out.reshape(-1, self.n_traits)[:] = g
+            return out
+        return g
+
+    def reward_max(self, gebv, n_envs, out=None):
+        self.calls["reward_max"] += 1
+        r = torch.from_numpy(co.reward_max(gebv.numpy().reshape(n_envs, -1)))
+        if out is not None:
+            out[:] = r
+            return out
+        return r
+
+    def topk(self, scores, k):
+        self.calls["topk"] += 1
+        s = scores.to(torch.float32).numpy()
+        s2 = s.reshape(-1, s.shape[-1])
+        out = np.stack([co.topk(row, k) for row in s2])
+        return torch.from_numpy(out.reshape(*s.shape[:-1], k))
+
+    def sync(self):
+        pass

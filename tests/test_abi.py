@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads, exports every symbol include/breedhip.h declares, its ctypes
+table matches the header, and its host-side RNG plumbing equals the oracle.  No GPU compute."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from breedgym_amd import _lib
+from breedgym_amd import rng as hrng
+from oracle import c_oracle as co
+
+HEADER = Path(__file__).resolve().parents[1] / "include" / "breedhip.h"
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(native_lib):
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(native_lib, s), f"{s} declared in breedhip.h but not exported"
+
+
+def test_ctypes_table_matches_header(native_lib):
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_errors(native_lib):
+    assert b"gfx950" in native_lib.bh_version()
+    # argument validation happens before any device work, so it is testable without a GPU
+    out = ctypes.c_void_p()
+    r = np.zeros(4, np.float32)
+    rc = native_lib.bh_create(0, 0, 1, r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                              r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(out))
+    assert rc == _lib.BH_ERR_BAD_ARG and b"n_markers" in native_lib.bh_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    rc = native_lib.bh_create(0, native_lib.bh_max_markers() + 1, 1,
+                              r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                              r.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(out))
+    assert rc == _lib.BH_ERR_UNSUPPORTED
+    assert native_lib.bh_row_pitch(None) == 0
+
+
+def test_no_device_fails_loudly(native_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from breedgym_amd import HipEngine
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipEngine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32))
+
+
+def test_product_never_imports_oracle():
+    root = Path(__file__).resolve().parents[1]
+    for f in list((root / "breedgym_amd").rglob("*.py")) + list((root / "breedgym_amd").rglob("*.h*")):
+        txt = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+        assert "breed_oracle" not in txt, f
+
+
+def test_host_rng_equals_oracle(native_lib):
+    for seed in (0, 7, 2**31 + 5, 2**32 - 1, 2**40 + 3):
+        assert np.array_equal(hrng.key(seed), co.key_from_seed(seed))
+    k = hrng.key(7)
+    for num in (1, 2, 3, 17, 401):
+        assert np.array_equal(hrng.split(k, num), co.split(k, num))
+    for n in (1, 2, 3, 64, 370, 1001, 70000):
+        assert np.array_equal(hrng.permutation(k, n), co.permutation(k, n)), n
+    f, nk = hrng.founders(k, 5, 370, 200)
+    fo, nko = co.founders(k, 5, 370, 200)
+    assert np.array_equal(f, fo) and np.array_equal(nk, nko)
+    with pytest.raises(ValueError):
+        hrng.founders(k, 2, 10, 11)
+
+
+def test_host_rng_golden(native_lib, golden_dir):
+    z = np.load(golden_dir / "golden_host_rng.npz")
+    f, k = hrng.founders(hrng.key(7), 4, 370, 200)
+    assert np.array_equal(f, z["founders"]) and np.array_equal(k, z["founders_key"])
+    assert np.array_equal(hrng.permutation(hrng.key(5), 70000)[:64], z["perm70000_head"])

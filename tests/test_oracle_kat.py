@@ -1,0 +1,153 @@
+"""CPU: pin the oracle -- published vectors, C-vs-NumPy agreement, committed golden fixtures,
+and the RNG-free invariants the domain offers."""
+import json
+
+import numpy as np
+import pytest
+from golden_util import CASES, GOLDEN, load_case
+
+from oracle import c_oracle as co
+from oracle import numpy_oracle as no
+
+KAT = json.loads((GOLDEN / "kat_published.json").read_text())
+
+
+@pytest.mark.parametrize("impl", ["c", "numpy"])
+def test_threefry_random123_kat(impl):
+    for v in KAT["threefry2x32_20"]:
+        if impl == "c":
+            got = co.threefry2x32(*v["key"], *v["ctr"])
+        else:
+            o0, o1 = no.threefry2x32(v["key"], np.uint32([v["ctr"][0]]), np.uint32([v["ctr"][1]]))
+            got = (int(o0[0]), int(o1[0]))
+        assert list(got) == v["out"]
+
+
+@pytest.mark.parametrize("mod", [co, no])
+def test_jax_documented_values(mod):
+    """`random.split(PRNGKey(0))`, `random.uniform(PRNGKey(0))` as printed in JAX's docs
+    (original, non-partitionable threefry layouts)."""
+    d = KAT["jax_docs_original_layout"]
+    k0 = mod.key_from_seed(0)
+    assert mod.split(k0, 2).tolist() == d["split_PRNGKey0_num2"]
+    bits = mod.random_bits(k0, 1)
+    u = co.uniform_f32(bits)[0]
+    assert abs(float(u) - d["uniform_PRNGKey0"]) < 5e-9
+    # normal = sqrt(2) * erfinv(uniform in (-1, 1)): same word, affine map
+    from scipy.special import erfinv
+
+    lo = np.nextafter(np.float32(-1), np.float32(0))
+    x = np.float32(u) * (np.float32(1) - lo) + lo
+    assert abs(float(np.sqrt(2) * erfinv(np.float64(x))) - d["normal_PRNGKey0"]) < 1e-6
+
+
+def test_threshold_equivalence(rng):
+    """(bits >> 9) < thr23(r)  <=>  uniform_f32(bits) < r, including r = 0, tiny, 0.5, >= 1."""
+    r = np.float32([0.0, -1.0, 1e-30, 2.0**-23, 2.0**-24, 1.1920929e-07, 0.0040950868, 0.5, 0.99999994, 1.0, 2.0])
+    r = np.concatenate([r, rng.random(64, dtype=np.float32) * np.float32(0.01)])
+    bits = np.concatenate([rng.integers(0, 2**32, 20000, dtype=np.uint64).astype(np.uint32),
+                           np.uint32([0, 1, 511, 512, 513, 0xFFFFFFFF, 0xFFFFFE00, 0x80000000])])
+    # also words sitting right at each threshold
+    thr = co.threshold23(r)
+    edge = np.array([(int(t) << 9) + d for t in thr for d in (-512, -1, 0, 1, 511, 512)], dtype=np.int64)
+    bits = np.concatenate([bits, np.clip(edge, 0, 2**32 - 1).astype(np.uint32)])
+    u = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1)
+    for rj, tj in zip(r, thr):
+        assert np.array_equal(u < rj, (bits >> np.uint32(9)) < tj), float(rj)
+
+
+def test_c_equals_numpy_random_shapes(rng):
+    for M in (1, 2, 3, 63, 64, 65, 127, 129, 1000, 1001):
+        E, NP, NO = 2, 5, 4
+        pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+        idx = rng.integers(-NP, NP + 2, (E, NO, 2), dtype=np.int32)  # incl. negatives and n, n+1
+        r = (rng.random(M) * 0.1).astype(np.float32)
+        r[0] = 0.5
+        for mode in (0, 1):
+            key = co.key_from_seed(int(rng.integers(0, 2**32)))
+            oc, kc, masks = co.cross(pool, idx, r, key, mode, return_masks=True)
+            on, kn = no.vec_step_cross(pool, idx, r, key, mode)
+            assert np.array_equal(oc, on) and np.array_equal(kc, kn), (M, mode)
+            # batched NumPy path (the B1 CPU baseline) agrees too
+            nidx = np.clip(np.where(idx < 0, idx + NP, idx), 0, NP - 1)
+            par = pool[np.arange(E)[:, None, None], nidx].reshape(E * NO, 2, M, 2)
+            if mode == 1:
+                ob, kb = no.cross_batched(par, r, key)
+                assert np.array_equal(ob.reshape(oc.shape), oc) and np.array_equal(kb, kc)
+            # closure: every offspring allele is one of the two alleles of the right parent
+            sel = np.take_along_axis(par.reshape(E, NO, 2, M, 2), masks[..., None].astype(np.int64), -1)[..., 0]
+            assert np.array_equal(sel.transpose(0, 1, 3, 2), oc)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_cross_and_gebv(name):
+    c = load_case(name)
+    for mod in ("c", "numpy"):
+        if mod == "c":
+            out, key, masks = co.cross(c["pool"], c["idx"], c["r"], co.key_from_seed(c["seed"]), c["rng_mode"],
+                                       return_masks=True)
+            assert np.array_equal(masks, c["masks"])
+        else:
+            out, key = no.vec_step_cross(c["pool"], c["idx"], c["r"], no.key_from_seed(c["seed"]), c["rng_mode"])
+        assert np.array_equal(out, c["out"]) and np.array_equal(key, c["new_key"])
+    g32, g64 = co.gebv(c["out"], c["effects"], want64=True)
+    assert np.array_equal(g32, c["gebv32"]) and np.allclose(g64, c["gebv64"], rtol=1e-13)
+    assert np.allclose(no.gebv(c["out"], c["effects"]), c["gebv64"], rtol=1e-12, atol=1e-9)
+
+
+def test_zero_recombination_inherits_whole_chromosomes():
+    """RecombRate == 0 everywhere (the reference's sample_genetic_map.txt): the only sites are
+    chromosome starts (r = 0.5), so inside a chromosome the mask is constant."""
+    c = load_case("golden_zero_recomb")
+    lens = np.load(GOLDEN / "golden_zero_recomb_chr_lens.npy")
+    start = 0
+    for L in lens:
+        seg = c["masks"][..., start : start + L]
+        assert np.all(seg == seg[..., :1])
+        start += L
+    assert start == c["masks"].shape[-1]
+
+
+def test_homozygous_parents_are_deterministic(rng):
+    M = 300
+    pool = np.repeat(rng.integers(0, 2, (1, 6, M, 1), dtype=np.uint8), 2, axis=-1)  # both alleles equal
+    idx = rng.integers(0, 6, (1, 10, 2), dtype=np.int32)
+    r = np.full(M, 0.3, np.float32)
+    out, _ = co.cross(pool, idx, r, co.key_from_seed(1))
+    for p in (0, 1):
+        assert np.array_equal(out[0, :, :, p], pool[0, idx[0, :, p], :, 0])
+
+
+def test_crossover_statistics():
+    """flip rate between markers m-1, m is r[m]; at marker 0 the mask is Bernoulli(r[0])."""
+    M, G = 64, 20000
+    r = np.linspace(0.0, 0.5, M).astype(np.float32)
+    r[0] = 0.5
+    keys = co.split(co.key_from_seed(3), G)
+    masks = np.stack([co.meiosis_mask(k, r) for k in keys[:4000]])
+    flips = np.concatenate([masks[:, :1], masks[:, 1:] ^ masks[:, :-1]], axis=1).mean(0)
+    se = np.sqrt(np.maximum(r * (1 - r), 1e-4) / len(masks))
+    assert np.all(np.abs(flips - r) < 5 * se + 1e-3)
+
+
+def test_host_rng_golden():
+    z = np.load(GOLDEN / "golden_host_rng.npz")
+    for mod in (co, no):
+        f, k = mod.founders(mod.key_from_seed(7), 4, 370, 200)
+        assert np.array_equal(f, z["founders"]) and np.array_equal(k, z["founders_key"])
+        perm = mod.permutation(mod.key_from_seed(5), 70000)
+        assert np.array_equal(perm[:64], z["perm70000_head"])
+        assert int((perm.astype(np.int64) * np.arange(70000)).sum()) == int(z["perm70000_sum"])
+        assert sorted(perm.tolist()) == list(range(70000))
+        assert np.array_equal(mod.topk(z["scores"], 50), z["top50"])
+    assert all(len(set(row.tolist())) == 200 for row in z["founders"])  # without replacement
+
+
+def test_gebv_matches_reference_formulas(rng):
+    """the two in-tree statements of the formula: optimize_diff_cross.py:16-17, index_functions.py:55"""
+    pop = rng.integers(0, 2, (5, 40, 2), dtype=np.uint8)
+    eff = rng.standard_normal((40, 3)).astype(np.float32)
+    a = np.dot(pop.sum(axis=-1), eff.astype(np.float64))
+    b = np.einsum("nmd,me->ne", pop.astype(np.float64), eff.astype(np.float64))
+    g32, g64 = co.gebv(pop, eff, want64=True)
+    assert np.allclose(g64, a, rtol=1e-13) and np.allclose(g64, b, rtol=1e-13)
