@@ -50,8 +50,22 @@ struct bh_ctx {
   int64_t M = 0, T = 0, pitch = 0;
   int32_t half = 0, nwh = 0, nw = 0, nvec = 0;
   int64_t effPitch = 0;
-  uint32_t *d_thrA = nullptr, *d_thrB = nullptr;
+  uint32_t *d_thrA = nullptr, *d_thrB = nullptr;  // 32-bit thresholds (thr23 << 9)
+  uint64_t *d_alwA = nullptr, *d_alwB = nullptr;  // site words of markers with r >= 1, or null
+  int64_t nthr = 0;
   double *d_eff = nullptr;  // (T, effPitch)
+  // crossover-mask buffers: the launch that streams generation g from d_Z[cur] also makes the
+  // masks of generation g+1 in d_Z[1 - cur] (cross_kernel's two roles)
+  uint8_t *d_Z[2] = {nullptr, nullptr};
+  int64_t z_cap[2] = {0, 0};  // bytes
+  bool prefetch = true;
+  struct {
+    bool valid = false;
+    int buf = 0;
+    uint32_t key0 = 0, key1 = 0;
+    int64_t B = 0;
+  } pf;
+  int last_buf = 1;
   // top-k scratch
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};
@@ -63,57 +77,128 @@ namespace {
 
 int waves_for(const bh_ctx *c) { return c->M <= 16384 ? 1 : 4; }
 
-size_t cross_lds_bytes(const bh_ctx *c, int waves, int tt) {
-  return (size_t)(4 * c->nwh + 2) * 8 + (size_t)16 * c->nw + (waves > 1 ? (size_t)waves * tt * 8 : 0);
-}
+size_t mask_group_lds(const bh_ctx *c) { return (size_t)(c->nwh + 1) * 32; }  // S[nwh + 1][4] u64
 
 template <int WAVES, int TT, int MODE>
-int launch_row(const bh_ctx *c, const bh::RowParams &p, size_t lds) {
-  auto kern = bh::row_kernel<WAVES, TT, MODE>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)p.n_rows), dim3(64 * WAVES), lds, c->stream, p);
+int launch_row(const bh_ctx *c, const bh::RowParams &p) {
+  hipLaunchKernelGGL((bh::row_kernel<WAVES, TT, MODE>), dim3((unsigned)p.n_blocks), dim3(256), 0, c->stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "row_kernel launch: %s", hipGetErrorString(e));
   return BH_OK;
 }
 
 template <int WAVES, int MODE>
-int launch_row_tt(const bh_ctx *c, const bh::RowParams &p, int tt, size_t lds) {
+int launch_row_tt(const bh_ctx *c, const bh::RowParams &p, int tt) {
   switch (tt) {
-    case 0: return launch_row<WAVES, 0, MODE>(c, p, lds);
-    case 1: return launch_row<WAVES, 1, MODE>(c, p, lds);
-    case 2: return launch_row<WAVES, 2, MODE>(c, p, lds);
-    case 4: return launch_row<WAVES, 4, MODE>(c, p, lds);
-    default: return launch_row<WAVES, 8, MODE>(c, p, lds);
+    case 0: return launch_row<WAVES, 0, MODE>(c, p);
+    case 1: return launch_row<WAVES, 1, MODE>(c, p);
+    case 2: return launch_row<WAVES, 2, MODE>(c, p);
+    case 4: return launch_row<WAVES, 4, MODE>(c, p);
+    default: return launch_row<WAVES, 8, MODE>(c, p);
   }
 }
 
 template <int MODE>
-int launch_row_mode(const bh_ctx *c, const bh::RowParams &p, int tt) {
+int launch_row_mode(const bh_ctx *c, bh::RowParams p, int tt) {
   const int waves = waves_for(c);
-  const size_t lds = MODE == bh::MODE_CROSS ? cross_lds_bytes(c, waves, tt)
-                                            : (waves > 1 ? (size_t)waves * tt * 8 : 0);
-  if (waves == 1) return launch_row_tt<1, MODE>(c, p, tt, lds);
-  return launch_row_tt<4, MODE>(c, p, tt, lds);
+  const int groups = 4 / waves;
+  p.n_blocks = (p.n_rows + groups - 1) / groups;
+  if (waves == 1) return launch_row_tt<1, MODE>(c, p, tt);
+  return launch_row_tt<4, MODE>(c, p, tt);
+}
+
+bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
+  const int groups = 4 / waves_for(c);
+  bh::MaskParams m{};
+  m.Z = c->d_Z[buf];
+  m.thrA = c->d_thrA;
+  m.thrB = c->d_thrB;
+  m.alwA = c->d_alwA;
+  m.alwB = c->d_alwB;
+  m.thr_bytes = (uint32_t)(c->nthr * 4);
+  m.zpitch = (int64_t)16 * c->nw;
+  m.M = (int32_t)c->M;
+  m.half = c->half;
+  m.nwh = c->nwh;
+  m.nw = c->nw;
+  m.n_rows = (int32_t)B;
+  m.n_blocks = (int32_t)((B + groups - 1) / groups);
+  m.group_lds = (int32_t)mask_group_lds(c);
+  m.key0 = key0;
+  m.key1 = key1;
+  m.nkeys = (uint32_t)(2 * B + 1);
+  return m;
+}
+
+template <typename K>
+int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
+  if (lds <= 64 * 1024) return BH_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+// crossover masks of B crosses keyed off `key` into d_Z[buf], in stream order (not overlapped)
+int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
+  const bh::MaskParams m = mask_params(c, buf, key0, key1, B);
+  const int waves = waves_for(c);
+  const size_t lds = (size_t)m.group_lds * (4 / waves);
+  if (waves == 1) {
+    hipLaunchKernelGGL(bh::mask_kernel<1>, dim3((unsigned)m.n_blocks), dim3(256), lds, c->stream, m);
+  } else {
+    if (int rc = allow_big_lds(c, bh::mask_kernel<4>, lds)) return rc;
+    hipLaunchKernelGGL(bh::mask_kernel<4>, dim3((unsigned)m.n_blocks), dim3(256), lds, c->stream, m);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+// one launch: waves 0-3 of every workgroup stream `rp` (generation g), waves 4-7 fill `mp`
+// (generation g+1).  Only for rows one wave handles (waves_for() == 1).
+template <int TT>
+int launch_cross_tt(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp) {
+  const size_t lds = (size_t)mp.group_lds * 4;
+  const int grid = rp.n_blocks > mp.n_blocks ? rp.n_blocks : mp.n_blocks;
+  hipLaunchKernelGGL(bh::cross_kernel<TT>, dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "cross_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+int launch_cross(bh_ctx *c, bh::RowParams rp, const bh::MaskParams &mp, int tt) {
+  rp.n_blocks = (rp.n_rows + 3) / 4;
+  switch (tt) {
+    case 0: return launch_cross_tt<0>(c, rp, mp);
+    case 1: return launch_cross_tt<1>(c, rp, mp);
+    case 2: return launch_cross_tt<2>(c, rp, mp);
+    case 4: return launch_cross_tt<4>(c, rp, mp);
+    default: return launch_cross_tt<8>(c, rp, mp);
+  }
+}
+
+// make d_Z[buf] hold at least `bytes`; growing it waits for everything that may still touch it
+int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
+  if (c->z_cap[buf] >= bytes) return BH_OK;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_Z[buf]) BH_HIP(hipFree(c->d_Z[buf]));
+  c->d_Z[buf] = nullptr;
+  c->z_cap[buf] = 0;
+  if (c->pf.valid && c->pf.buf == buf) c->pf.valid = false;
+  BH_HIP(hipMalloc(&c->d_Z[buf], (size_t)bytes));
+  c->z_cap[buf] = bytes;
+  return BH_OK;
 }
 
 int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 ? 2 : tcount <= 4 ? 4 : 8; }
 
 bh::RowParams base_params(const bh_ctx *c) {
   bh::RowParams p{};
-  p.thrA = c->d_thrA;
-  p.thrB = c->d_thrB;
   p.eff = c->d_eff;
   p.pitch = c->pitch;
   p.effPitch = c->effPitch;
-  p.M = (int32_t)c->M;
-  p.half = c->half;
-  p.nwh = c->nwh;
-  p.nw = c->nw;
+  p.zpitch = (int64_t)16 * c->nw;
   p.nvec = c->nvec;
   p.T = (int32_t)c->T;
   return p;
@@ -193,11 +278,30 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   c->nvec = (int32_t)(c->pitch / 16);
   c->effPitch = (int64_t)c->nvec * 8;
 
-  const int64_t nthr = (int64_t)c->nwh * 64;
+  // thresholds for the raw 32-bit compare: uniform(bits) < r  <=>  (bits >> 9) < t23  <=>
+  // bits < (t23 << 9); t23 = 2^23 (r >= 1, always) does not fit and becomes an always-set bit.
+  const int64_t nthr = (int64_t)(c->nwh + 16) * 64;  // + the trips the kernel prefetches ahead
+  c->nthr = nthr;
   std::vector<uint32_t> thrA(nthr, 0u), thrB(nthr, 0u);
+  std::vector<uint64_t> alwA((size_t)c->nwh, 0ull), alwB((size_t)c->nwh, 0ull);
+  bool any_always = false;
   for (int64_t j = 0; j < c->half; ++j) {
-    thrA[j] = bh::threshold23(recomb_vec[j]);
-    if (j + c->half < n_markers) thrB[j] = bh::threshold23(recomb_vec[j + c->half]);
+    const uint32_t ta = bh::threshold23(recomb_vec[j]);
+    if (ta >> 23) {
+      alwA[(size_t)(j >> 6)] |= 1ull << (j & 63);
+      any_always = true;
+    } else {
+      thrA[j] = ta << 9;
+    }
+    if (j + c->half < n_markers) {
+      const uint32_t tb = bh::threshold23(recomb_vec[j + c->half]);
+      if (tb >> 23) {
+        alwB[(size_t)(j >> 6)] |= 1ull << (j & 63);
+        any_always = true;
+      } else {
+        thrB[j] = tb << 9;
+      }
+    }
   }
   std::vector<double> eff((size_t)std::max<int64_t>(1, n_traits * c->effPitch), 0.0);
   for (int64_t t = 0; t < n_traits; ++t)
@@ -219,6 +323,12 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   BH_HIP_C(hipMalloc(&c->d_eff, eff.size() * sizeof(double)));
   BH_HIP_C(hipMemcpy(c->d_thrA, thrA.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
   BH_HIP_C(hipMemcpy(c->d_thrB, thrB.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (any_always) {
+    BH_HIP_C(hipMalloc(&c->d_alwA, alwA.size() * sizeof(uint64_t)));
+    BH_HIP_C(hipMalloc(&c->d_alwB, alwB.size() * sizeof(uint64_t)));
+    BH_HIP_C(hipMemcpy(c->d_alwA, alwA.data(), alwA.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    BH_HIP_C(hipMemcpy(c->d_alwB, alwB.data(), alwB.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   BH_HIP_C(hipMemcpy(c->d_eff, eff.data(), eff.size() * sizeof(double), hipMemcpyHostToDevice));
 #undef BH_HIP_C
   *out = c;
@@ -228,8 +338,12 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
 int bh_destroy(bh_ctx *c) {
   if (!c) return BH_OK;
   (void)hipSetDevice(c->device);
+  for (int i = 0; i < 2; ++i)
+    if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
+  if (c->d_alwA) (void)hipFree(c->d_alwA);
+  if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
   for (int i = 0; i < 2; ++i) {
     if (c->d_cand_s[i]) (void)hipFree(c->d_cand_s[i]);
@@ -332,29 +446,64 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
     const uint8_t *out_end = d_out + rows * c->pitch;
     if (d_out < pool_end && d_pool < out_end) return fail(BH_ERR_BAD_ARG, "bh_cross: d_out aliases d_pool");
 
+    // ---- this generation's masks: made by the previous call's launch, or made now
+    const int64_t zbytes = B * 16 * c->nw;
+    int buf;
+    if (c->pf.valid && c->pf.key0 == sim_key[0] && c->pf.key1 == sim_key[1] && c->pf.B == B) {
+      buf = c->pf.buf;
+    } else {  // not predicted: first call, new seed, new batch size
+      buf = 1 - c->last_buf;
+      if (int rc = ensure_z(c, buf, zbytes)) return rc;
+      if (int rc = launch_masks(c, buf, sim_key[0], sim_key[1], B)) return rc;
+    }
+    c->pf.valid = false;
+    c->last_buf = buf;
+  }
+
+  // Simulator.cross: keys = split(key, 2B+1); key <- keys[0]
+  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)(2 * B + 1), 0u);
+
+  if (rows > 0) {
+    const int buf = c->last_buf;
     bh::RowParams p = base_params(c);
     p.src = d_pool;
     p.out = d_out;
     p.idx = d_idx;
     p.gebv = d_gebv;
+    p.Z = c->d_Z[buf];
     p.n_pool = (int32_t)pool_rows;
     p.n_out = (int32_t)n_out;
     p.n_rows = (int32_t)rows;
-    p.key0 = sim_key[0];
-    p.key1 = sim_key[1];
-    p.nkeys = (uint32_t)(2 * B + 1);
     p.rng_shared = rng_mode == BH_RNG_SHARED_ENVS;
     const bool fused = d_gebv && c->T <= kMaxFusedTraits;
     p.t0 = 0;
     p.tcount = fused ? (int32_t)c->T : 0;
-    if (int rc = launch_row_mode<bh::MODE_CROSS>(c, p, tt_for(p.tcount))) return rc;
+    if (c->prefetch && waves_for(c) == 1) {
+      // run ahead: the next generation's masks need only the advanced key and the batch size, so
+      // the same launch makes them (mask role) while it streams this generation (row role)
+      if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
+      p.Z = c->d_Z[buf];
+      const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B);
+      if (int rc = launch_cross(c, p, mp, tt_for(p.tcount))) return rc;
+      c->pf.valid = true;
+      c->pf.buf = 1 - buf;
+      c->pf.key0 = nk.x;
+      c->pf.key1 = nk.y;
+      c->pf.B = B;
+    } else {
+      if (int rc = launch_row_mode<bh::MODE_CROSS>(c, p, tt_for(p.tcount))) return rc;
+    }
     if (d_gebv && !fused)
       if (int rc = gebv_chunks(c, d_out, rows, d_gebv, 0)) return rc;
   }
-  // Simulator.cross: keys = split(key, 2B+1); key <- keys[0]
-  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)(2 * B + 1), 0u);
   sim_key[0] = nk.x;
   sim_key[1] = nk.y;
+  return BH_OK;
+}
+
+int bh_set_mask_prefetch(bh_ctx *c, int enable) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  c->prefetch = enable != 0;
   return BH_OK;
 }
 

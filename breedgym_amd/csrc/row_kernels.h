@@ -1,24 +1,29 @@
 // Device kernels for the BreedGym hot path on gfx950 (MI355X, CDNA4, wave64).
 //
-// One workgroup of WAVES wavefronts owns one output row (one cross / one gathered founder /
-// one individual whose GEBV is wanted) and walks the marker axis:
+// A cross is done by two kernels that meet in a small mask buffer:
 //
-//   phase A  (MODE_CROSS)  Threefry-2x32 per marker pair (j, j+half) for both gametes; the
-//            Bernoulli(r) recombination sites leave the wave as ballots -> 64-bit site words
-//            in LDS.  One Threefry call serves two markers (JAX's original random_bits
-//            layout hashes the counter vector in two halves), and each threshold load is
-//            shared by the two gametes.
-//   phase B  inclusive prefix-XOR over the site bit strings (6 shift-xor steps inside a
-//            64-bit word, ballot+popcount across words) -> crossover masks in LDS, stored
-//            byte-interleaved so that phase C fetches both gametes' 8 mask bits with one
-//            ds_read_u16.
-//   phase C  16-byte coalesced reads of both parents (8 markers x 2 alleles per lane),
-//            one v_perm_b32 per output dword picks the allele the masks point at, 16-byte
-//            coalesced store of the offspring, and the GEBV dot product is accumulated in
-//            f64 from the bytes already in registers (no re-read of the offspring).
+//   mask_kernel  (VALU-bound)  Threefry-2x32 per marker pair (j, j+half) for both gametes of a
+//     cross; the Bernoulli(r) recombination sites leave the wave as ballots -> 64-bit site
+//     words in LDS (phase A); an inclusive prefix-XOR over the site strings (6 shift-xor steps
+//     inside a 64-bit word, ballot+popcount across words) turns them into crossover masks,
+//     written to HBM byte-interleaved, 2 bits per marker = M/4 bytes per cross (phase B).
+//     One Threefry call serves two markers (JAX's original random_bits layout hashes the
+//     counter vector in two halves) and each threshold load is shared by the two gametes.
+//     The masks depend on the key chain and the cross slot only -- not on the parents -- so
+//     they are computed one generation AHEAD: cross_kernel is a single launch whose workgroups
+//     take one of two roles, "row" (stream generation g with the masks made by the previous
+//     launch) or "mask" (make the masks of generation g+1).  The two kinds of workgroup share
+//     every CU, so the VALU-bound Threefry work runs under the memory-bound streaming.
+//   row_kernel   (HBM-bound)   16-byte coalesced reads of both parents through the action
+//     indices (8 markers x 2 alleles per lane; the reference's materialised parent gather,
+//     vec_env.py:89-90, is just an address here), one v_perm_b32 per output dword picks the
+//     allele the mask bits point at, 16-byte coalesced store of the offspring, and the GEBV
+//     dot product is accumulated in f64 from the bytes already in registers.  The same kernel
+//     in MODE_GATHER / MODE_GEBV is the founder gather of reset() and the standalone GEBV.
 //
-// The parent gather of the reference (vec_env.py:89-90) is folded into the address of the
-// phase-C loads: parents are never materialised.
+// A group of WAVES wavefronts owns one row.  Workgroups are always 256 threads = 4 waves, one
+// per SIMD of the CU: with WAVES = 1 a workgroup carries four independent rows, with
+// WAVES = 4 (long rows) the whole workgroup shares one.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,23 +34,38 @@ namespace bh {
 
 enum { MODE_CROSS = 0, MODE_GATHER = 1, MODE_GEBV = 2 };
 
+struct MaskParams {
+  uint8_t *Z;            // (n_rows, zpitch) interleaved crossover masks, out
+  const uint32_t *thrA;  // [(nwh+16)*64] 32-bit thresholds of markers [0, half), zero padded
+  const uint32_t *thrB;  // [(nwh+16)*64] 32-bit thresholds of markers [half, M), zero padded
+  const uint64_t *alwA;  // [nwh] site words that are always set (r >= 1), or null if there are none
+  const uint64_t *alwB;
+  int64_t zpitch;        // bytes per cross = 16 * nw
+  int32_t M, half, nwh, nw;
+  int32_t n_rows;     // B: crosses with their own keys
+  int32_t n_blocks;   // workgroups with mask waves = ceil(n_rows / (4 / WAVES))
+  int32_t group_lds;  // LDS bytes per group (multiple of 16)
+  uint32_t thr_bytes; // size of thrA / thrB in bytes (buffer descriptor range)
+  uint32_t key0, key1;  // the call's simulator key
+  uint32_t nkeys;       // 2*B + 1 keys are split off it
+};
+
 struct RowParams {
-  const uint8_t *src;    // cross: (E, n_pool, pitch) pool; gather: (n_pool, pitch); gebv: (rows, pitch)
-  uint8_t *out;          // (rows, pitch) or null (gebv)
-  const int32_t *idx;    // cross: (rows, 2); gather: (rows); gebv: null
-  float *gebv;           // (rows, T) or null
-  const uint32_t *thrA;  // [nwh*64] thresholds of markers [0, half), zero padded
-  const uint32_t *thrB;  // [nwh*64] thresholds of markers [half, M), zero padded
-  const double *eff;     // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
-  int64_t pitch;         // bytes per genotype row (multiple of 16)
-  int64_t effPitch;      // doubles per trait (= 8 * nvec)
-  int32_t M, half, nwh, nw, nvec;
+  const uint8_t *src;  // cross: (E, n_pool, pitch) pool; gather: (n_pool, pitch); gebv: (rows, pitch)
+  uint8_t *out;        // (rows, pitch) or null (gebv)
+  const int32_t *idx;  // cross: (rows, 2); gather: (rows); gebv: null
+  float *gebv;         // (rows, T) or null
+  const uint8_t *Z;    // cross: (B, zpitch) masks from mask_kernel
+  const double *eff;   // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
+  int64_t pitch;       // bytes per genotype row (multiple of 16)
+  int64_t effPitch;    // doubles per trait (= 8 * nvec)
+  int64_t zpitch;
+  int32_t nvec;
   int32_t n_pool, n_out;  // rows per env in src / out (cross); n_pool = src rows (gather)
-  int32_t n_rows;         // total output rows = grid size
+  int32_t n_rows;         // total output rows
+  int32_t n_blocks;       // grid size = ceil(n_rows / (4 / WAVES))
   int32_t T, t0, tcount;  // GEBV row stride, first trait and trait count of this launch
-  uint32_t key0, key1;    // the call's simulator key
-  uint32_t nkeys;         // 2*B + 1 keys are split off it
-  int32_t rng_shared;     // 1: key index from the env-local cross index
+  int32_t rng_shared;     // 1: mask row = env-local cross index (all envs share the masks)
 };
 
 // Blocks b, b+8, b+16.. are dealt to the same XCD (round-robin dispatch).  Hand every XCD a
@@ -72,178 +92,297 @@ __device__ __forceinline__ uint64_t prefix_xor64(uint64_t x) {
   return x;
 }
 
-// 64 site bits of markers [64w, 64w+64) out of the two half-strings.
-// SA holds markers [0, half) from bit 0 of SA[0]; SB holds markers [half, M) from bit 0 of SB[0].
-__device__ __forceinline__ uint64_t site_word(const uint64_t *SA, const uint64_t *SB, int w, int half) {
+// Site words live in LDS as S[t][4] = {A(g0), B(g0), A(g1), B(g1)}: A words hold markers
+// [0, half) from bit 0 of word 0, B words markers [half, M) from bit 0 of word 0.
+// Returns the 64 site bits of markers [64w, 64w+64) of gamete g.
+__device__ __forceinline__ uint64_t site_word(const uint64_t *S, int g, int w, int half) {
+  const uint64_t *SA = S + 2 * g, *SB = S + 2 * g + 1;
   const int base = w << 6;
-  if (base + 64 <= half) return SA[w];
+  if (base + 64 <= half) return SA[4 * w];
   if (base >= half) {
-    const int off = base - half, k = off >> 6, s = off & 63;
-    const uint64_t lo = SB[k];
-    return s ? ((lo >> s) | (SB[k + 1] << (64 - s))) : lo;
+    const int off = base - half, k = off >> 6, sh = off & 63;
+    const uint64_t lo = SB[4 * k];
+    return sh ? ((lo >> sh) | (SB[4 * (k + 1)] << (64 - sh))) : lo;
   }
-  return SA[w] | (SB[0] << (half - base));
+  return SA[4 * w] | (SB[0] << (half - base));
+}
+
+// Synchronise the WAVES waves of one group.  A single wave needs no barrier: its LDS
+// operations execute in program order; the fence only pins that order for the compiler.
+template <int WAVES>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (WAVES == 4) {
+    __syncthreads();  // the group is the whole workgroup
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---- Threefry-2x32-20 for two key pairs at once, hand-placed ----------------------------------
+// Measured on gfx950 (tools/tf_variants.hip, tools/tf_nops.hip): a dependent
+// v_add_u32 -> v_alignbit_b32 -> v_xor_b32 stream issues at ~13 cycles per round, and at ~9 when
+// one scalar no-op follows the add, for 2..8 waves per SIMD alike; hipcc's own stream for the
+// same arithmetic takes ~25 % longer than this one.  Operands: %0,%1 = x0,x1 of chain A,
+// %2,%3 = chain B; per chain eight scalar key words
+//   k1, k2+1, k2, k0+2, k0, k1+3, k2+4, k0+5      (k2 = k0 ^ k1 ^ 0x1BD11BDA)
+// The caller has already added (k0, k1) to the counters.
+#define BH_RA(r) "v_add_u32 %0, %0, %1\n s_nop 0\n v_alignbit_b32 %1, %1, %1, " #r "\n v_xor_b32 %1, %1, %0\n"
+#define BH_RB(r) "v_add_u32 %2, %2, %3\n s_nop 0\n v_alignbit_b32 %3, %3, %3, " #r "\n v_xor_b32 %3, %3, %2\n"
+#define BH_IA(ka, kb) "v_add_u32 %0, " ka ", %0\n s_nop 0\n v_add_u32 %1, " kb ", %1\n"
+#define BH_IB(ka, kb) "v_add_u32 %2, " ka ", %2\n s_nop 0\n v_add_u32 %3, " kb ", %3\n"
+// rotate-left by R is v_alignbit by 32 - R: {13,15,26,6} -> {19,17,6,26}; {17,29,16,24} -> {15,3,16,8}
+#define BH_TFA                                                                                          \
+  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%4", "%5") BH_RA(15) BH_RA(3) BH_RA(16) BH_RA(8) BH_IA("%6", "%7")  \
+  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%8", "%9") BH_RA(15) BH_RA(3) BH_RA(16) BH_RA(8) BH_IA("%4", "%10") \
+  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%6", "%11")
+#define BH_TFB                                                                                                  \
+  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%12", "%13") BH_RB(15) BH_RB(3) BH_RB(16) BH_RB(8) BH_IB("%14", "%15") \
+  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%16", "%17") BH_RB(15) BH_RB(3) BH_RB(16) BH_RB(8) BH_IB("%12", "%18") \
+  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%14", "%19")
+
+struct KeySched {  // the eight scalar words one chain needs
+  uint32_t w[8];
+};
+__device__ __forceinline__ KeySched key_sched(uint32_t k0, uint32_t k1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  return {{k1, k2 + 1u, k2, k0 + 2u, k0, k1 + 3u, k2 + 4u, k0 + 5u}};
+}
+
+// `wave` = this wave's index among the four waves that play the role in this workgroup.
+template <int WAVES>
+__device__ __forceinline__ void mask_role(const MaskParams &p, const int block, const int wave, uint8_t *lds_raw) {
+  static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or the whole workgroup");
+  constexpr int GROUPS = 4 / WAVES;
+  const int lane = threadIdx.x & 63;
+  const int grp = wave / WAVES, wv = wave % WAVES;
+  const int tid = wv * 64 + lane;
+  const int c = __builtin_amdgcn_readfirstlane(block * GROUPS + grp);
+  if (c >= p.n_rows) return;  // only possible for WAVES == 1, whose waves never meet at a barrier
+  uint64_t *S = reinterpret_cast<uint64_t *>(lds_raw + (size_t)grp * p.group_lds);  // [nwh + 1][4]
+
+  // ---- gamete keys: keys = split(sim_key, nkeys); gamete (c, q) owns keys[1 + 2c + q]; its
+  //      recombination key is split(gamete_key, 2)[0].  Lanes 0..3 carry the 4 words.
+  uint32_t rk00, rk01, rk10, rk11;
+  {
+    const uint32_t q = (lane >> 1) & 1u, w = lane & 1u;
+    const uint32_t kidx = 1u + 2u * (uint32_t)c + q;
+    const uint32_t gw = iota_word_even(p.key0, p.key1, 2u * p.nkeys, 2u * kidx + w);
+    const uint32_t g0 = __shfl(gw, lane & ~1), g1 = __shfl(gw, lane | 1);
+    const uint32_t rw = threefry2x32(g0, g1, w, w + 2u).x;
+    rk00 = __builtin_amdgcn_readlane(rw, 0);
+    rk01 = __builtin_amdgcn_readlane(rw, 1);
+    rk10 = __builtin_amdgcn_readlane(rw, 2);
+    rk11 = __builtin_amdgcn_readlane(rw, 3);
+  }
+  const KeySched ka = key_sched(rk00, rk01), kb = key_sched(rk10, rk11);
+
+  // ---- phase A: recombination sites.  Everything around the Threefry block is kept off the
+  // vector ALU where possible: thresholds come through a buffer descriptor (lane offset in a
+  // VGPR, trip offset in an SGPR: no address arithmetic), one trip ahead of their use; the
+  // compare is on the raw 32-bit word (thresholds pre-shifted); markers with r >= 1 are OR-ed in
+  // as whole scalar words; the four ballots of a trip go to LDS with two 16-byte stores.
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)p.thrA, 0, p.thr_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)p.thrB, 0, p.thr_bytes, 0x00020000);
+  const uint32_t voff = lane * 4u;
+  const uint32_t c1a = rk01 + (uint32_t)p.half, c1b = rk11 + (uint32_t)p.half;
+  const bool odd = (p.M & 1) != 0;
+
+#define BH_TRIP(T_, J_, TA_, TB_)                                                                                   \
+  {                                                                                                                 \
+    uint32_t a0 = (J_) + rk00, a1 = (J_) + c1a, b0 = (J_) + rk10, b1 = (J_) + c1b;                                  \
+    if (odd && (T_) == p.nwh - 1) { /* the pad counter (0) of an odd-length stream */                               \
+      const bool pad = (J_) + (uint32_t)p.half >= (uint32_t)p.M;                                                    \
+      a1 = pad ? rk01 : a1;                                                                                         \
+      b1 = pad ? rk11 : b1;                                                                                         \
+    }                                                                                                               \
+    asm volatile(BH_TFA BH_TFB                                                                                      \
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                           \
+                 : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
+                   "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),              \
+                   "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                         \
+    uint64_t sA0 = __ballot(a0 < (TA_)), sB0 = __ballot(a1 < (TB_));                                                \
+    uint64_t sA1 = __ballot(b0 < (TA_)), sB1 = __ballot(b1 < (TB_));                                                \
+    if (p.alwA) {                                                                                                   \
+      const uint64_t xa = p.alwA[(T_)], xb = p.alwB[(T_)];                                                          \
+      sA0 |= xa;                                                                                                    \
+      sA1 |= xa;                                                                                                    \
+      sB0 |= xb;                                                                                                    \
+      sB1 |= xb;                                                                                                    \
+    }                                                                                                               \
+    if (lane == 0) {                                                                                                \
+      ulonglong2 *dstw = reinterpret_cast<ulonglong2 *>(S + 4 * (T_));                                              \
+      dstw[0] = make_ulonglong2(sA0, sB0);                                                                          \
+      dstw[1] = make_ulonglong2(sA1, sB1);                                                                          \
+    }                                                                                                               \
+  }
+
+  {
+    int t = wv;
+    uint32_t j = (uint32_t)wv * 64u + lane;
+    uint32_t soff = (uint32_t)wv * 256u;
+    constexpr uint32_t STEP = 256u * WAVES;
+    uint32_t tA0 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff, 0);
+    uint32_t tB0 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff, 0);
+    uint32_t tA1 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + STEP, 0);
+    uint32_t tB1 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + STEP, 0);
+    while (t < p.nwh) {
+      BH_TRIP(t, j, tA0, tB0)
+      tA0 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + 2u * STEP, 0);
+      tB0 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + 2u * STEP, 0);
+      if (t + WAVES < p.nwh) BH_TRIP(t + WAVES, j + 64u * WAVES, tA1, tB1)
+      tA1 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + 3u * STEP, 0);
+      tB1 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + 3u * STEP, 0);
+      t += 2 * WAVES;
+      j += 128u * WAVES;
+      soff += 2u * STEP;
+    }
+  }
+#undef BH_TRIP
+  if (tid == 0) {
+    S[4 * p.nwh + 1] = 0;  // the word behind the last B words (funnel shifts read one ahead)
+    S[4 * p.nwh + 3] = 0;
+  }
+  group_sync<WAVES>();
+
+  // ---- phase B: crossover masks = inclusive prefix-XOR of the site strings
+  if (wv == 0) {
+    uint8_t *Z = p.Z + (int64_t)c * p.zpitch;
+    uint32_t carry0 = 0, carry1 = 0;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int w0 = 0; w0 < p.nw; w0 += 64) {
+      const int w = w0 + lane;
+      uint64_t x0 = 0, x1 = 0;
+      if (w < p.nw) {
+        x0 = prefix_xor64(site_word(S, 0, w, p.half));
+        x1 = prefix_xor64(site_word(S, 1, w, p.half));
+      }
+      const uint64_t par0 = __ballot((x0 >> 63) != 0), par1 = __ballot((x1 >> 63) != 0);
+      if ((__popcll(par0 & below) & 1u) ^ carry0) x0 = ~x0;
+      if ((__popcll(par1 & below) & 1u) ^ carry1) x1 = ~x1;
+      carry0 ^= __popcll(par0) & 1u;
+      carry1 ^= __popcll(par1) & 1u;
+      if (w < p.nw) {
+        // bytes x0.b0 x1.b0 x0.b1 x1.b1 ... so that markers 8v..8v+7 are one u16 at Z + 2v
+        const uint32_t a0 = (uint32_t)x0, a1 = (uint32_t)(x0 >> 32);
+        const uint32_t b0 = (uint32_t)x1, b1 = (uint32_t)(x1 >> 32);
+        uint4 z;
+        z.x = __builtin_amdgcn_perm(b0, a0, 0x05010400u);
+        z.y = __builtin_amdgcn_perm(b0, a0, 0x07030602u);
+        z.z = __builtin_amdgcn_perm(b1, a1, 0x05010400u);
+        z.w = __builtin_amdgcn_perm(b1, a1, 0x07030602u);
+        *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
+      }
+    }
+  }
+}
+
+// offspring dword k of one 16-byte vector: dword k holds markers 2k, 2k+1 as bytes
+// [m0 a0, m0 a1, m1 a0, m1 a1]; output byte (marker, p) = parent p's byte (marker, mask_p).
+// zz = the vector's 16 mask bits (low byte gamete 0, high byte gamete 1).  nibble =
+// [g0(2k) g0(2k+1) g1(2k) g1(2k+1)]; the multiply drops its bits onto bit 0 of selector bytes
+// 0, 2, 1, 3 of a v_perm_b32 whose sources are {parent 1 dword, parent 0 dword}.
+__device__ __forceinline__ uint32_t select_dword(uint32_t zz, int k, uint32_t aw, uint32_t bw) {
+  const uint32_t nib = ((zz >> (2 * k)) & 3u) | (((zz >> (8 + 2 * k)) & 3u) << 2);
+  return __builtin_amdgcn_perm(bw, aw, ((nib * 0x00208041u) & 0x01010101u) | 0x06020400u);
+}
+
+template <int TT>
+__device__ __forceinline__ void gebv_accumulate(double (&acc)[TT > 0 ? TT : 1], const uint4 o, const RowParams &p,
+                                                int v) {
+  if constexpr (TT > 0) {
+    // dosage of markers (2k, 2k+1) = bytes 0 and 2 of  w + (w >> 8)   (alleles are 0/1)
+    const uint32_t s0 = o.x + (o.x >> 8), s1 = o.y + (o.y >> 8);
+    const uint32_t s2 = o.z + (o.z >> 8), s3 = o.w + (o.w >> 8);
+    const double d0 = (double)(s0 & 0xffu), d1 = (double)((s0 >> 16) & 0xffu);
+    const double d2 = (double)(s1 & 0xffu), d3 = (double)((s1 >> 16) & 0xffu);
+    const double d4 = (double)(s2 & 0xffu), d5 = (double)((s2 >> 16) & 0xffu);
+    const double d6 = (double)(s3 & 0xffu), d7 = (double)((s3 >> 16) & 0xffu);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      if (t < p.tcount) {
+        const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)t * p.effPitch + 8 * (int64_t)v);
+        const double2 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+        double s = acc[t];
+        s = fma(d0, e0.x, s);
+        s = fma(d1, e0.y, s);
+        s = fma(d2, e1.x, s);
+        s = fma(d3, e1.y, s);
+        s = fma(d4, e2.x, s);
+        s = fma(d5, e2.y, s);
+        s = fma(d6, e3.x, s);
+        s = fma(d7, e3.y, s);
+        acc[t] = s;
+      }
+    }
+  }
 }
 
 template <int WAVES, int TT, int MODE>
-__global__ __launch_bounds__(64 * WAVES) void row_kernel(const RowParams p) {
-  extern __shared__ __align__(16) uint64_t lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int c = xcd_row(blockIdx.x, p.n_rows);
+__device__ __forceinline__ void row_role(const RowParams &p, const int block, const int wave, double *red) {
+  static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or the whole workgroup");
+  constexpr int GROUPS = 4 / WAVES;
+  constexpr int STRIDE = 64 * WAVES;
+  const int lane = threadIdx.x & 63;
+  const int grp = wave / WAVES, wv = wave % WAVES;
+  const int tid = wv * 64 + lane;  // thread index inside the group
+  // wave-uniform by construction; readfirstlane tells the compiler, so row addressing is scalar
+  const int c = __builtin_amdgcn_readfirstlane(xcd_row(block, p.n_blocks) * GROUPS + grp);
+  if (c >= p.n_rows) return;  // only possible for WAVES == 1, whose waves never meet at a barrier
 
   const uint8_t *src0 = nullptr, *src1 = nullptr;
-  int e = 0, i = c;
+  const uint16_t *Z16 = nullptr;
   if constexpr (MODE == MODE_CROSS) {
-    e = c / p.n_out;
-    i = c - e * p.n_out;
+    const int e = c / p.n_out, i = c - e * p.n_out;
     const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
     const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
     src0 = p.src + ((int64_t)e * p.n_pool + i0) * p.pitch;
     src1 = p.src + ((int64_t)e * p.n_pool + i1) * p.pitch;
+    Z16 = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
   } else if constexpr (MODE == MODE_GATHER) {
     src0 = p.src + (int64_t)norm_index(p.idx[c], p.n_pool) * p.pitch;
   } else {
     src0 = p.src + (int64_t)c * p.pitch;
   }
 
-  // LDS carve-up (MODE_CROSS): site words of both gametes, then the interleaved masks
-  uint64_t *SA0 = lds;
-  uint64_t *SB0 = SA0 + p.nwh;
-  uint64_t *SA1 = SB0 + p.nwh + 1;
-  uint64_t *SB1 = SA1 + p.nwh;
-  uint8_t *Z = reinterpret_cast<uint8_t *>(SB1 + p.nwh + 1);  // 16 * nw bytes, 16-B aligned
-  double *red = reinterpret_cast<double *>(MODE == MODE_CROSS ? Z + 16 * (int64_t)p.nw : (uint8_t *)lds);
+  // Row waves share their SIMD with a VALU-bound mask wave.  VALU issue is arbitrated by
+  // priority first: the little arithmetic a row wave has between its loads should not queue
+  // behind Threefry, or the memory pipes drain.
+  __builtin_amdgcn_s_setprio(3);
 
-  if constexpr (MODE == MODE_CROSS) {
-    // ---- gamete keys: keys = split(sim_key, nkeys); gamete (b,q) owns keys[1+2b+q];
-    //      its recombination key is split(gamete_key, 2)[0].  Lanes 0..3 carry the 4 words.
-    uint32_t rk00, rk01, rk10, rk11;
-    {
-      const uint32_t b = p.rng_shared ? (uint32_t)i : (uint32_t)c;
-      const uint32_t q = (lane >> 1) & 1u, w = lane & 1u;
-      const uint32_t kidx = 1u + 2u * b + q;
-      const uint32_t gw = iota_word_even(p.key0, p.key1, 2u * p.nkeys, 2u * kidx + w);
-      const uint32_t g0 = __shfl(gw, lane & ~1), g1 = __shfl(gw, lane | 1);
-      const uint32_t rw = threefry2x32(g0, g1, w, w + 2u).x;
-      rk00 = __builtin_amdgcn_readlane(rw, 0);
-      rk01 = __builtin_amdgcn_readlane(rw, 1);
-      rk10 = __builtin_amdgcn_readlane(rw, 2);
-      rk11 = __builtin_amdgcn_readlane(rw, 3);
-    }
-
-    // ---- phase A: recombination sites
-    for (int t = wv; t < p.nwh; t += WAVES) {
-      const uint32_t j = (uint32_t)t * 64u + lane;
-      const uint32_t tA = p.thrA[j], tB = p.thrB[j];
-      uint32_t c1 = j + (uint32_t)p.half;
-      if (c1 >= (uint32_t)p.M) c1 = 0u;  // the pad counter of an odd-length stream
-      const u32x2 a = threefry2x32(rk00, rk01, j, c1);
-      const u32x2 b = threefry2x32(rk10, rk11, j, c1);
-      const uint64_t sA0 = __ballot((a.x >> 9) < tA);
-      const uint64_t sB0 = __ballot((a.y >> 9) < tB);
-      const uint64_t sA1 = __ballot((b.x >> 9) < tA);
-      const uint64_t sB1 = __ballot((b.y >> 9) < tB);
-      if (lane == 0) {
-        SA0[t] = sA0;
-        SB0[t] = sB0;
-        SA1[t] = sA1;
-        SB1[t] = sB1;
-      }
-    }
-    if (tid == 0) {
-      SB0[p.nwh] = 0;
-      SB1[p.nwh] = 0;
-    }
-    __syncthreads();
-
-    // ---- phase B: crossover masks = inclusive prefix-XOR of the site strings
-    if (wv == 0) {
-      uint32_t carry0 = 0, carry1 = 0;
-      const uint64_t below = (1ull << lane) - 1ull;
-      for (int w0 = 0; w0 < p.nw; w0 += 64) {
-        const int w = w0 + lane;
-        uint64_t x0 = 0, x1 = 0;
-        if (w < p.nw) {
-          x0 = prefix_xor64(site_word(SA0, SB0, w, p.half));
-          x1 = prefix_xor64(site_word(SA1, SB1, w, p.half));
-        }
-        const uint64_t par0 = __ballot((x0 >> 63) != 0), par1 = __ballot((x1 >> 63) != 0);
-        if ((__popcll(par0 & below) & 1u) ^ carry0) x0 = ~x0;
-        if ((__popcll(par1 & below) & 1u) ^ carry1) x1 = ~x1;
-        carry0 ^= __popcll(par0) & 1u;
-        carry1 ^= __popcll(par1) & 1u;
-        if (w < p.nw) {
-          // bytes x0.b0 x1.b0 x0.b1 x1.b1 ... so that markers 8v..8v+7 are one u16 at Z+2v
-          const uint32_t a0 = (uint32_t)x0, a1 = (uint32_t)(x0 >> 32);
-          const uint32_t b0 = (uint32_t)x1, b1 = (uint32_t)(x1 >> 32);
-          uint4 z;
-          z.x = __builtin_amdgcn_perm(b0, a0, 0x05010400u);
-          z.y = __builtin_amdgcn_perm(b0, a0, 0x07030602u);
-          z.z = __builtin_amdgcn_perm(b1, a1, 0x05010400u);
-          z.w = __builtin_amdgcn_perm(b1, a1, 0x07030602u);
-          *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- phase C: stream the row(s)
   double acc[TT > 0 ? TT : 1];
 #pragma unroll
   for (int t = 0; t < (TT > 0 ? TT : 1); ++t) acc[t] = 0.0;
-
   uint8_t *dst = (MODE == MODE_GEBV) ? nullptr : p.out + (int64_t)c * p.pitch;
-  const uint16_t *Z16 = reinterpret_cast<const uint16_t *>(Z);
 
-  for (int v = tid; v < p.nvec; v += 64 * WAVES) {
-    const uint4 a = *reinterpret_cast<const uint4 *>(src0 + 16 * (int64_t)v);
-    uint4 o = a;
+  // two 16-byte vectors per lane and trip: all loads of a trip are issued before the first use
+  for (int v = tid; v < p.nvec; v += 2 * STRIDE) {
+    const int v1 = v + STRIDE;
+    const bool has1 = v1 < p.nvec;
+    const int w1 = has1 ? v1 : v;
+    const uint4 a0 = *reinterpret_cast<const uint4 *>(src0 + 16 * (int64_t)v);
+    const uint4 a1 = *reinterpret_cast<const uint4 *>(src0 + 16 * (int64_t)w1);
+    uint4 o0 = a0, o1 = a1;
     if constexpr (MODE == MODE_CROSS) {
-      const uint4 b = *reinterpret_cast<const uint4 *>(src1 + 16 * (int64_t)v);
-      const uint32_t zz = Z16[v];
-      // dword k holds markers 2k, 2k+1 as bytes [m0 a0, m0 a1, m1 a0, m1 a1]; output byte
-      // (marker, p) = parent p's byte (marker, mask_p[marker]).  nibble = [g0(2k) g0(2k+1)
-      // g1(2k) g1(2k+1)]; the multiply drops its bits onto bit 0 of selector bytes 0,2,1,3.
-#define BH_SEL(k, aw, bw)                                                                   \
-  __builtin_amdgcn_perm(                                                                    \
-      bw, aw,                                                                               \
-      ((((zz >> (2 * k)) & 3u) | (((zz >> (8 + 2 * k)) & 3u) << 2)) * 0x00208041u & 0x01010101u) | \
-          0x06020400u)
-      o.x = BH_SEL(0, a.x, b.x);
-      o.y = BH_SEL(1, a.y, b.y);
-      o.z = BH_SEL(2, a.z, b.z);
-      o.w = BH_SEL(3, a.w, b.w);
-#undef BH_SEL
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(src1 + 16 * (int64_t)v);
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(src1 + 16 * (int64_t)w1);
+      const uint32_t z0 = Z16[v], z1 = Z16[w1];
+      o0.x = select_dword(z0, 0, a0.x, b0.x);
+      o0.y = select_dword(z0, 1, a0.y, b0.y);
+      o0.z = select_dword(z0, 2, a0.z, b0.z);
+      o0.w = select_dword(z0, 3, a0.w, b0.w);
+      o1.x = select_dword(z1, 0, a1.x, b1.x);
+      o1.y = select_dword(z1, 1, a1.y, b1.y);
+      o1.z = select_dword(z1, 2, a1.z, b1.z);
+      o1.w = select_dword(z1, 3, a1.w, b1.w);
     }
-    if constexpr (MODE != MODE_GEBV) *reinterpret_cast<uint4 *>(dst + 16 * (int64_t)v) = o;
-
-    if constexpr (TT > 0) {
-      // dosage of markers (2k, 2k+1) = bytes 0 and 2 of  w + (w >> 8)   (alleles are 0/1)
-      const uint32_t s0 = o.x + (o.x >> 8), s1 = o.y + (o.y >> 8);
-      const uint32_t s2 = o.z + (o.z >> 8), s3 = o.w + (o.w >> 8);
-      const double d0 = (double)(s0 & 0xffu), d1 = (double)((s0 >> 16) & 0xffu);
-      const double d2 = (double)(s1 & 0xffu), d3 = (double)((s1 >> 16) & 0xffu);
-      const double d4 = (double)(s2 & 0xffu), d5 = (double)((s2 >> 16) & 0xffu);
-      const double d6 = (double)(s3 & 0xffu), d7 = (double)((s3 >> 16) & 0xffu);
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        if (t < p.tcount) {
-          const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)t * p.effPitch + 8 * (int64_t)v);
-          const double2 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
-          double s = acc[t];
-          s = fma(d0, e0.x, s);
-          s = fma(d1, e0.y, s);
-          s = fma(d2, e1.x, s);
-          s = fma(d3, e1.y, s);
-          s = fma(d4, e2.x, s);
-          s = fma(d5, e2.y, s);
-          s = fma(d6, e3.x, s);
-          s = fma(d7, e3.y, s);
-          acc[t] = s;
-        }
-      }
+    if constexpr (MODE != MODE_GEBV) {
+      *reinterpret_cast<uint4 *>(dst + 16 * (int64_t)v) = o0;
+      if (has1) *reinterpret_cast<uint4 *>(dst + 16 * (int64_t)v1) = o1;
     }
+    gebv_accumulate<TT>(acc, o0, p, v);
+    if (has1) gebv_accumulate<TT>(acc, o1, p, v1);
   }
 
   if constexpr (TT > 0) {
@@ -255,7 +394,6 @@ __global__ __launch_bounds__(64 * WAVES) void row_kernel(const RowParams p) {
       acc[t] = s;
     }
     if constexpr (WAVES > 1) {
-      __syncthreads();  // everyone is done with Z before `red` (which may alias it) is written
       if (lane == 0)
         for (int t = 0; t < TT; ++t) red[wv * TT + t] = acc[t];
       __syncthreads();
@@ -271,6 +409,41 @@ __global__ __launch_bounds__(64 * WAVES) void row_kernel(const RowParams p) {
       for (int t = 0; t < TT; ++t)
         if (t < p.tcount) p.gebv[(int64_t)c * p.T + p.t0 + t] = (float)acc[t];
     }
+  }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(256) void mask_kernel(const MaskParams p) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  mask_role<WAVES>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), lds_raw);
+}
+
+template <int WAVES, int TT, int MODE>
+__global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
+  __shared__ double red[4 * (TT > 0 ? TT : 1)];
+  row_role<WAVES, TT, MODE>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), red);
+}
+
+// One launch, two roles, for rows that one wave handles (WAVES = 1).  A workgroup is 8 waves:
+// waves 0-3 stream four rows of generation g (`rp`, with the masks the previous launch made),
+// waves 4-7 make the masks of four crosses of generation g+1 (`mp`).  A workgroup's waves are
+// dealt to the CU's four SIMDs in turn, so each SIMD gets one memory-bound and one VALU-bound
+// wave per workgroup whatever the dispatcher does with workgroups.  (Giving whole workgroups
+// one role each was measured to put each role on half of the CUs only.)  The two halves never
+// meet at a barrier.
+template <int TT>
+__global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const MaskParams mp) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  const int wave = (int)(threadIdx.x >> 6);
+#if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation.sh)
+  if (wave < 4) return;
+#elif defined(BH_ABLATE_NO_MASKROLE)
+  if (wave >= 4) return;
+#endif
+  if (wave < 4) {
+    if ((int)blockIdx.x < rp.n_blocks) row_role<1, TT, MODE_CROSS>(rp, (int)blockIdx.x, wave, nullptr);
+  } else {
+    if ((int)blockIdx.x < mp.n_blocks) mask_role<1>(mp, (int)blockIdx.x, wave - 4, lds_raw);
   }
 }
 

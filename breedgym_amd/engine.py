@@ -202,5 +202,9 @@ class HipEngine(EngineBase):
         _lib.check(self._L.bh_topk(self._h, s2.data_ptr(), s2.shape[0], s2.shape[1], int(k), out.data_ptr()))
         return out.reshape(*s.shape[:-1], int(k))
 
+    def set_mask_prefetch(self, enable: bool) -> None:
+        """Run-ahead of the next generation's crossover masks on a side stream (default on)."""
+        _lib.check(self._L.bh_set_mask_prefetch(self._h, int(bool(enable))))
+
     def sync(self) -> None:
         _lib.check(self._L.bh_sync(self._h))

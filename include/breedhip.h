@@ -102,6 +102,14 @@ int bh_cross(bh_ctx *ctx, const uint8_t *d_pool, int64_t n_envs, int64_t pool_ro
              const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
              uint8_t *d_out, float *d_gebv);
 
+/* Run-ahead of the crossover masks.  The masks of a generation depend on the key chain and
+ * the batch size only, never on the parents, so every bh_cross launch also makes the masks of
+ * the NEXT generation: its workgroups take two roles that share each CU, a memory-bound one
+ * that streams the current generation and a VALU-bound one that runs Threefry for the next.
+ * A call whose key or batch size was not predicted (first call, re-seed, new shape) makes its
+ * masks in stream order first.  Results never depend on this switch.  Default: enabled. */
+int bh_set_mask_prefetch(bh_ctx *ctx, int enable);
+
 /* Row gather + GEBV: `_random_selection` / `germplasm[selected_indices]` + `get_info`
  * (vec_env.py:22-27,126-129; breedgym.py:121-125).  d_idx (n_rows) int32 into d_src
  * (src_rows, pitch); d_out (n_rows, pitch); d_gebv (n_rows, T) or NULL. */

@@ -234,3 +234,55 @@ def test_c3_wheat_scale_properties():
     got8, _, g8 = run_cross(eng, geno, idx[:, :8], 3, 0)
     assert np.array_equal(got8, ref)
     assert gebv_close(g8, co.gebv(ref, gm.marker_effects, want64=True)[1], gm.marker_effects)
+
+
+@pytest.mark.parametrize("prefetch", [True, False])
+def test_mask_prefetch_never_changes_results(prefetch, rng):
+    """The run-ahead of next generation's masks is invisible: hits, a re-seed (miss), a batch-size
+    change (miss), a mode change, with the switch on and off -- always the oracle's bits."""
+    M = 777
+    r = (rng.random(M) * 0.05).astype(np.float32)
+    r[::100] = 0.5
+    eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+    eng = make_engine(r, eff)
+    eng.set_mask_prefetch(prefetch)
+    E, n = 3, 10
+    cur = rng.integers(0, 2, (E, n, M, 2), dtype=np.uint8)
+    rows = eng.upload_population(cur.reshape(E * n, M, 2))
+    key = co.key_from_seed(1).copy()
+    okey = co.key_from_seed(1)
+    plan = [(n, 0), (n, 0), (n, 0), ("reseed", 0), (n, 0), (7, 0), (7, 0), (7, 1), (7, 1), (12, 1), (12, 0)]
+    n_pool = n
+    for step, (n_out, mode) in enumerate(plan):
+        if n_out == "reseed":
+            key = co.key_from_seed(99).copy()
+            okey = co.key_from_seed(99)
+            continue
+        idx = rng.integers(0, n_pool, (E, n_out, 2), dtype=np.int32)
+        out = eng.empty_population(E * n_out)
+        g = eng.empty((E, n_out, 1), torch.float32)
+        eng.cross(rows, E, n_pool, torch.from_numpy(idx).to(eng.device), n_out, key, mode, out, g)
+        ref, okey = co.cross(cur, idx, r, okey, mode)
+        got = eng.download_population(out).view(np.uint8).reshape(ref.shape)
+        assert np.array_equal(got, ref), f"step {step}"
+        assert np.array_equal(key, okey)
+        assert gebv_close(g.cpu().numpy(), co.gebv(ref, eff, want64=True)[1], eff)
+        rows, cur, n_pool = out, ref, n_out
+    if step == 5:
+        eng.set_mask_prefetch(not prefetch)  # flipping it mid-run is safe too
+
+
+@pytest.mark.parametrize("M", [65, 130, 1000])
+def test_recombination_probability_edges(M, rng):
+    """r = 0, tiny, 0.5, the largest float below 1, exactly 1 and above 1 (always a site)."""
+    r = rng.choice(np.float32([0.0, 1e-30, 2.0**-23, 2.0**-24, 1e-4, 0.5, 0.99999994, 1.0, 1.5]), M).astype(np.float32)
+    r[0] = 1.0
+    r[M - 1] = 1.0
+    r[M // 2] = 2.0
+    pool = rng.integers(0, 2, (2, 4, M, 2), dtype=np.uint8)
+    idx = rng.integers(0, 4, (2, 9, 2), dtype=np.int32)
+    eng = make_engine(r, np.ones((M, 1), np.float32))
+    for mode in (0, 1):
+        got, key, _ = run_cross(eng, pool, idx, 17, mode)
+        ref, refkey = co.cross(pool, idx, r, co.key_from_seed(17), mode)
+        assert np.array_equal(got, ref) and np.array_equal(key, refkey)
