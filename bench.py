@@ -33,10 +33,11 @@ N_GERMPLASM, N_MARKERS, N_ENVS, N_PER_ENV, N_GENERATIONS = 370, 10_000, 16, 256,
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(gm, geno, seconds_hint=10.0):
+def cpu_baseline(gm, geno, rng_mode, seconds_hint=8.0):
     """The CPU oracle (a from-scratch port: the reference's chromax/JAX CPU path cannot be
     installed here or on the GPU box) timed on this host on a bounded sample of the same
-    workload: whole 4096-cross generations of 370x10k, all cores (OpenMP over crosses)."""
+    workload: whole 4096-cross generations of 370x10k (cross + GEBV + reward), OpenMP over
+    crosses on the box's CPU share (16 hardware threads per GPU)."""
     from oracle import c_oracle as co
     from oracle import numpy_oracle as no
 
@@ -45,26 +46,28 @@ def cpu_baseline(gm, geno, seconds_hint=10.0):
     pool = geno.view(np.uint8)[np.stack([rng.permutation(N_GERMPLASM)[:n] for _ in range(E)])]
     idx = rng.integers(0, n, (E, n, 2), dtype=np.int32)
     key = co.key_from_seed(0)
-    cores = co.num_threads()
+    cores = min(16, len(os.sched_getaffinity(0)))
+    co.set_num_threads(cores)
 
     def one_generation():
-        out, _ = co.cross(pool, idx, gm.recombination_vec, key, 1)
+        out, _ = co.cross(pool, idx, gm.recombination_vec, key, rng_mode)
         g = co.gebv(out, gm.marker_effects)
         co.reward_max(g)
 
     t0 = time.perf_counter()
-    one_generation()  # also the warm-up; a generation is O(seconds) on a few cores
+    one_generation()  # also the warm-up
     first = time.perf_counter() - t0
-    reps = int(max(1, min(20, seconds_hint / max(first, 1e-3))))
+    reps = int(max(1, min(50, seconds_hint / max(first, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
         one_generation()
     dt = (time.perf_counter() - t0) / reps
     res = {
         "value": E * n / dt, "unit": "crosses/s", "cores": cores, "kind": "port",
-        "sample": f"{reps} generations of {E}x{n}={E*n} crosses x {M} markers (C oracle, OpenMP, cross+GEBV+reward)",
+        "sample": f"{reps} generations of {E}x{n}={E*n} crosses x {M} markers (C oracle, OpenMP, "
+                  f"cross+GEBV+reward, same RNG sharing as the GPU run)",
     }
-    # single-thread C and the unfused NumPy restatement on 256 crosses
+    # single-thread C and the unfused NumPy restatement on one env's 256 crosses
     co.set_num_threads(1)
     t0 = time.perf_counter()
     out1, _ = co.cross(pool[:1], idx[:1], gm.recombination_vec, key, 1)
@@ -77,6 +80,44 @@ def cpu_baseline(gm, geno, seconds_hint=10.0):
     no.gebv(o, gm.marker_effects)
     res["numpy_restatement_crosses_per_s"] = n / (time.perf_counter() - t0)
     return res
+
+
+def time_steps(env, actions, steps, warmup, barrier):
+    import torch
+
+    for i in range(warmup):
+        env.step(actions[i % len(actions)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(actions[i % len(actions)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    return dt
+
+
+def time_cross_launches(env, actions, reps):
+    """HIP events around `reps` back-to-back launches of the hot-path kernel alone (the fused
+    two-role cross_kernel: streams this generation, makes the next one's masks)."""
+    import torch
+
+    eng = env.simulator.engine
+    E, n = env.num_envs, env._n
+    rows_in = env._rows
+    out = eng.empty_population(E * n)
+    gebv = eng.empty((E, n, eng.n_traits), torch.float32)
+    key = np.ascontiguousarray(env.simulator.random_key.copy())
+    for i in range(5):
+        eng.cross(rows_in, E, n, actions[i % len(actions)], n, key, env._rng_mode, out, gebv)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for i in range(reps):
+        eng.cross(rows_in, E, n, actions[i % len(actions)], n, key, env._rng_mode, out, gebv)
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
 
 
 def main():
@@ -108,56 +149,50 @@ def main():
 
     gm = synthetic_genetic_map(N_MARKERS, n_chr=10, n_traits=1, seed=1)
     geno = synthetic_genotypes(N_GERMPLASM, N_MARKERS, seed=0)
-    env = VecBreedGym(
-        num_envs=N_ENVS, initial_population=geno, individual_per_gen=N_PER_ENV, num_generations=N_GENERATIONS,
-        autoreset=True, reward_shaping=True, env_rng="independent", sync_rewards=False, genetic_map=gm,
-    )
+
+    def make_env(env_rng):
+        return VecBreedGym(
+            num_envs=N_ENVS, initial_population=geno, individual_per_gen=N_PER_ENV, num_generations=N_GENERATIONS,
+            autoreset=True, reward_shaping=True, env_rng=env_rng, sync_rewards=False, genetic_map=gm,
+        )
+
+    # Headline: the drop-in configuration.  env_rng="shared" is what the reference computes -- its
+    # jax.vmap over an un-batched simulator key hands every env the same gamete keys
+    # (vec_env.py:75-77) -- so per step the Threefry work is n x 2 gametes, applied to E x n crosses.
+    env = make_env("shared")
     dev = env.device
     arng = np.random.default_rng(2 + rank)
     actions = [
         torch.from_numpy(arng.integers(0, N_PER_ENV, (N_ENVS, N_PER_ENV, 2), dtype=np.int32)).to(dev)
         for _ in range(16)
     ]
-    env.reset(seed=100 + rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        env.step(actions[i % len(actions)])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        env.step(actions[i % len(actions)])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
+    env.reset(seed=100 + rank)
+    dt = time_steps(env, actions, args.steps, args.warmup, barrier)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
     crosses_per_step = N_ENVS * N_PER_ENV
+    kern_ms = time_cross_launches(env, actions, max(20, args.steps))
 
-    # ---- the dominant kernel (fused cross+GEBV) alone: HIP events around K back-to-back launches
-    eng = env.simulator.engine
-    rows_in, n_pool = env._rows, env._n
-    out = eng.empty_population(crosses_per_step)
-    gebv = eng.empty((N_ENVS, N_PER_ENV, 1), torch.float32)
-    key = np.ascontiguousarray(env.simulator.random_key.copy())
-    for i in range(5):
-        eng.cross(rows_in, N_ENVS, n_pool, actions[i % 16], N_PER_ENV, key, 1, out, gebv)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    kreps = max(20, args.steps)
-    torch.cuda.synchronize()
-    ev0.record()
-    for i in range(kreps):
-        eng.cross(rows_in, N_ENVS, n_pool, actions[i % 16], N_PER_ENV, key, 1, out, gebv)
-    ev1.record()
-    torch.cuda.synchronize()
-    kern_ms = ev0.elapsed_time(ev1) / kreps
-    alg_bytes = 6 * N_MARKERS * crosses_per_step  # 2 parents x 2M read + 2M written per cross
+    # The same steps with an independent Threefry stream per cross (an extension: not what the
+    # reference computes).  VALU-bound: 2 x 10k x 36 integer ops per cross.
+    env_i = make_env("independent")
+    env_i.reset(seed=100 + rank)
+    dt_i = time_steps(env_i, actions, args.steps, args.warmup, barrier)
+    ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+    kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
+
+    # algorithmic bytes per launch: 2 parents x 2M read + 2M written per cross
+    alg_bytes = 6 * N_MARKERS * crosses_per_step
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
@@ -182,21 +217,29 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: 370x10k germplasm, 16 envs x 256 = 4096 crosses/gen, GEBV reward, "
-                            "10-generation episodes with autoreset",
-                "n_markers": N_MARKERS, "crosses_per_step_per_gpu": crosses_per_step, "env_rng": "independent",
+                "workload": "BASELINE configs[1]: 370x10k germplasm, 16 envs x 256 = 4096 crosses/gen, GEBV reward "
+                            "every step, 10-generation episodes with autoreset",
+                "n_markers": N_MARKERS, "crosses_per_step_per_gpu": crosses_per_step,
+                "env_rng": "shared (reference semantics: vmap over an un-batched key, vec_env.py:75-77)",
                 "sharding": "envs across ranks, no data-path collective",
             },
             "roofline": {
-                "kernel": "row_kernel<1,1,MODE_CROSS> (fused gather+meiosis+GEBV)",
+                "kernel": "cross_kernel<1,4> (row role: gather+select+GEBV stream; mask role: next generation's Threefry)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "kernel_crosses_per_s": crosses_per_step / (kern_ms * 1e-3),
             },
+            "independent_rng": {
+                "note": "one Threefry stream per cross (env_rng='independent', an extension); VALU-bound",
+                "value": world * args.steps * crosses_per_step / float(ti.item()),
+                "ms_per_step": float(ti.item()) / args.steps * 1e3,
+                "kernel_ms": kern_ms_i,
+                "achieved_GBps": alg_bytes / (kern_ms_i * 1e-3) / 1e9,
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(gm, geno)
+            line["cpu_baseline"] = cpu_baseline(gm, geno, 0)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

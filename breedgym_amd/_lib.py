@@ -90,6 +90,7 @@ SIGNATURES = {
     "bh_key_split": (_int, [_u32p, _i64, _u32p]),
     "bh_permutation": (_int, [_u32p, _i64, _i32p]),
     "bh_founders": (_int, [_u32p, _i64, _i64, _i64, _i32p]),
+    "bh_founders_device": (_int, [_vp, _u32p, _i64, _i64, _i64, _vp]),
 }
 
 

@@ -107,8 +107,9 @@ int launch_row_mode(const bh_ctx *c, bh::RowParams p, int tt) {
   return launch_row_tt<4, MODE>(c, p, tt);
 }
 
-bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
-  const int groups = 4 / waves_for(c);
+// `waves` = waves per cross in the mask role (1 or 4)
+bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, int waves) {
+  const int groups = 4 / waves;
   bh::MaskParams m{};
   m.Z = c->d_Z[buf];
   m.thrA = c->d_thrA;
@@ -141,8 +142,8 @@ int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
 
 // crossover masks of B crosses keyed off `key` into d_Z[buf], in stream order (not overlapped)
 int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
-  const bh::MaskParams m = mask_params(c, buf, key0, key1, B);
   const int waves = waves_for(c);
+  const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves);
   const size_t lds = (size_t)m.group_lds * (4 / waves);
   if (waves == 1) {
     hipLaunchKernelGGL(bh::mask_kernel<1>, dim3((unsigned)m.n_blocks), dim3(256), lds, c->stream, m);
@@ -156,27 +157,31 @@ int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
 }
 
 // one launch: waves 0-3 of every workgroup stream `rp` (generation g), waves 4-7 fill `mp`
-// (generation g+1).  Only for rows one wave handles (waves_for() == 1).
-template <int TT>
+// (generation g+1) with MW waves per cross.  Only for rows one wave handles (waves_for() == 1).
+template <int TT, int MW>
 int launch_cross_tt(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp) {
-  const size_t lds = (size_t)mp.group_lds * 4;
+  const size_t lds = (size_t)mp.group_lds * (4 / MW);
   const int grid = rp.n_blocks > mp.n_blocks ? rp.n_blocks : mp.n_blocks;
-  hipLaunchKernelGGL(bh::cross_kernel<TT>, dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
+  hipLaunchKernelGGL((bh::cross_kernel<TT, MW>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "cross_kernel launch: %s", hipGetErrorString(e));
   return BH_OK;
 }
 
-int launch_cross(bh_ctx *c, bh::RowParams rp, const bh::MaskParams &mp, int tt) {
-  rp.n_blocks = (rp.n_rows + 3) / 4;
+template <int MW>
+int launch_cross_mw(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp, int tt) {
   switch (tt) {
-    case 0: return launch_cross_tt<0>(c, rp, mp);
-    case 1: return launch_cross_tt<1>(c, rp, mp);
-    case 2: return launch_cross_tt<2>(c, rp, mp);
-    case 4: return launch_cross_tt<4>(c, rp, mp);
-    default: return launch_cross_tt<8>(c, rp, mp);
+    case 0: return launch_cross_tt<0, MW>(c, rp, mp);
+    case 1: return launch_cross_tt<1, MW>(c, rp, mp);
+    case 2: return launch_cross_tt<2, MW>(c, rp, mp);
+    case 4: return launch_cross_tt<4, MW>(c, rp, mp);
+    default: return launch_cross_tt<8, MW>(c, rp, mp);
   }
 }
+
+// few crosses need masks (they are shared by all envs, or the batch is small): put four waves on
+// each so that the mask role is as short as the streaming beside it
+int mask_waves_for_runahead(int64_t B) { return B * 4 <= 2048 ? 4 : 1; }
 
 // make d_Z[buf] hold at least `bytes`; growing it waits for everything that may still touch it
 int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
@@ -483,8 +488,12 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
       // the same launch makes them (mask role) while it streams this generation (row role)
       if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
       p.Z = c->d_Z[buf];
-      const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B);
-      if (int rc = launch_cross(c, p, mp, tt_for(p.tcount))) return rc;
+      const int mw = mask_waves_for_runahead(B);
+      const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw);
+      p.n_blocks = (p.n_rows + 3) / 4;
+      if (int rc = mw == 1 ? launch_cross_mw<1>(c, p, mp, tt_for(p.tcount))
+                           : launch_cross_mw<4>(c, p, mp, tt_for(p.tcount)))
+        return rc;
       c->pf.valid = true;
       c->pf.buf = 1 - buf;
       c->pf.key0 = nk.x;
@@ -618,6 +627,47 @@ int bh_topk(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t
   return BH_OK;
 }
 
+int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                       int32_t *d_out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !d_out))
+    return fail(BH_ERR_BAD_ARG, "bh_founders_device: need 0 <= n <= n_germplasm");
+  if (n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: too many envs");
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u);
+  if (n_envs * n > 0) {
+    if (n_germplasm > 8192) {  // beyond one workgroup's LDS: draw on the host, copy the indices
+      std::vector<int32_t> h((size_t)(n_envs * n));
+      uint32_t k[2] = {env_key[0], env_key[1]};
+      if (int rc = bh_founders(k, n_envs, n_germplasm, n, h.data())) return rc;
+      BH_HIP(hipMemcpyAsync(d_out, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+      BH_HIP(hipStreamSynchronize(c->stream));
+    } else {
+      bh::FoundersParams p{};
+      p.out = d_out;
+      p.key0 = env_key[0];
+      p.key1 = env_key[1];
+      p.E = (int32_t)n_envs;
+      p.N = (int32_t)n_germplasm;
+      p.n = (int32_t)n;
+      p.P = 2;
+      while (p.P < n_germplasm) p.P <<= 1;
+      p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_germplasm)) / std::log(4294967295.0));
+      const size_t lds = (size_t)p.P * 16;
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::founders_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(founders LDS): %s", hipGetErrorString(e));
+      }
+      const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, p.P / 2));
+      hipLaunchKernelGGL(bh::founders_kernel, dim3((unsigned)n_envs), dim3(threads), lds, c->stream, p);
+      BH_HIP(hipGetLastError());
+    }
+  }
+  env_key[0] = nk.x;
+  env_key[1] = nk.y;
+  return BH_OK;
+}
+
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]) {
   key[0] = 0u;  // jax with x64 disabled drops the high word
   key[1] = (uint32_t)(seed & 0xFFFFFFFFull);
@@ -635,12 +685,15 @@ int bh_key_split(const uint32_t key[2], int64_t num, uint32_t *out) {
 
 int bh_permutation(const uint32_t key_in[2], int64_t n, int32_t *out) {
   if (!key_in || n < 0 || (n > 0 && !out) || n > 0x7FFFFFFF) return fail(BH_ERR_BAD_ARG, "bh_permutation: bad arguments");
-  // jax `_shuffle`: ceil(3 ln n / ln(2^32 - 1)) rounds of a stable sort by fresh random words
+  // jax `_shuffle`: ceil(3 ln n / ln(2^32 - 1)) rounds of a stable sort by fresh random words.
+  // Sorting (random word << 32 | current position) with an ordinary sort IS that stable sort.
   uint32_t key[2] = {key_in[0], key_in[1]};
   const int rounds = (int)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n)) / std::log(4294967295.0));
-  std::vector<int32_t> x((size_t)n), y((size_t)n);
-  std::vector<uint32_t> bits((size_t)n);
-  std::vector<int32_t> order((size_t)n);
+  thread_local std::vector<uint64_t> kv;
+  thread_local std::vector<int32_t> x, y;
+  kv.resize((size_t)n);
+  x.resize((size_t)n);
+  y.resize((size_t)n);
   std::iota(x.begin(), x.end(), 0);
   const int64_t L = n + (n & 1), h = L / 2;
   for (int rd = 0; rd < rounds; ++rd) {
@@ -650,12 +703,11 @@ int bh_permutation(const uint32_t key_in[2], int64_t n, int32_t *out) {
     for (int64_t i = 0; i < h; ++i) {  // random_bits(sub, n): odd n is padded with a 0 counter
       const uint32_t c1 = (i + h < n) ? (uint32_t)(i + h) : 0u;
       const bh::u32x2 o = bh::threefry2x32(sub.x, sub.y, (uint32_t)i, c1);
-      bits[(size_t)i] = o.x;
-      if (i + h < n) bits[(size_t)(i + h)] = o.y;
+      kv[(size_t)i] = ((uint64_t)o.x << 32) | (uint64_t)i;
+      if (i + h < n) kv[(size_t)(i + h)] = ((uint64_t)o.y << 32) | (uint64_t)(i + h);
     }
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return bits[(size_t)a] < bits[(size_t)b]; });
-    for (int64_t i = 0; i < n; ++i) y[(size_t)i] = x[(size_t)order[(size_t)i]];
+    std::sort(kv.begin(), kv.end());
+    for (int64_t i = 0; i < n; ++i) y[(size_t)i] = x[(size_t)(uint32_t)kv[(size_t)i]];
     x.swap(y);
   }
   std::copy(x.begin(), x.end(), out);

@@ -107,18 +107,8 @@ __device__ __forceinline__ uint64_t site_word(const uint64_t *S, int g, int w, i
   return SA[4 * w] | (SB[0] << (half - base));
 }
 
-// Synchronise the WAVES waves of one group.  A single wave needs no barrier: its LDS
-// operations execute in program order; the fence only pins that order for the compiler.
-template <int WAVES>
-__device__ __forceinline__ void group_sync() {
-  if constexpr (WAVES == 4) {
-    __syncthreads();  // the group is the whole workgroup
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
+// How the WAVES waves of a mask group meet between phase A and phase B.
+enum { SYNC_WAVE = 0, SYNC_BLOCK = 1, SYNC_COUNTER = 2 };
 
 // ---- Threefry-2x32-20 for two key pairs at once, hand-placed ----------------------------------
 // Measured on gfx950 (tools/tf_variants.hip, tools/tf_nops.hip): a dependent
@@ -151,9 +141,17 @@ __device__ __forceinline__ KeySched key_sched(uint32_t k0, uint32_t k1) {
 }
 
 // `wave` = this wave's index among the four waves that play the role in this workgroup.
-template <int WAVES>
-__device__ __forceinline__ void mask_role(const MaskParams &p, const int block, const int wave, uint8_t *lds_raw) {
-  static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or the whole workgroup");
+// SYNC says how the group's waves hand phase A's site words to the wave that runs phase B:
+//   SYNC_WAVE    one wave per cross: program order (LDS operations of a wave execute in order)
+//   SYNC_BLOCK   the workgroup is the group: __syncthreads()
+//   SYNC_COUNTER four mask waves next to four row waves that must not be held up: every mask
+//                wave bumps an LDS counter when its site words are written, wave 0 waits for it.
+//                `counter` was zeroed before a workgroup barrier at kernel entry.
+template <int WAVES, int SYNC>
+__device__ __forceinline__ void mask_role(const MaskParams &p, const int block, const int wave, uint8_t *lds_raw,
+                                          unsigned *counter) {
+  static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or four");
+  static_assert((WAVES == 1) == (SYNC == SYNC_WAVE), "one wave needs no hand-off, four need one");
   constexpr int GROUPS = 4 / WAVES;
   const int lane = threadIdx.x & 63;
   const int grp = wave / WAVES, wv = wave % WAVES;
@@ -244,7 +242,22 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     S[4 * p.nwh + 1] = 0;  // the word behind the last B words (funnel shifts read one ahead)
     S[4 * p.nwh + 3] = 0;
   }
-  group_sync<WAVES>();
+  if constexpr (SYNC == SYNC_WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else if constexpr (SYNC == SYNC_BLOCK) {
+    __syncthreads();
+  } else {
+    // one-way hand-off inside a workgroup (all of whose waves are resident): no wave ever waits
+    // for wave 0, so the wait below always ends; it is bounded all the same
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wv != 0) return;
+    for (int spin = 0; spin < (1 << 24); ++spin) {
+      if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)WAVES) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
 
   // ---- phase B: crossover masks = inclusive prefix-XOR of the site strings
   if (wv == 0) {
@@ -415,7 +428,7 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
 template <int WAVES>
 __global__ __launch_bounds__(256) void mask_kernel(const MaskParams p) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
-  mask_role<WAVES>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), lds_raw);
+  mask_role<WAVES, WAVES == 1 ? SYNC_WAVE : SYNC_BLOCK>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), lds_raw, nullptr);
 }
 
 template <int WAVES, int TT, int MODE>
@@ -424,17 +437,24 @@ __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
   row_role<WAVES, TT, MODE>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), red);
 }
 
-// One launch, two roles, for rows that one wave handles (WAVES = 1).  A workgroup is 8 waves:
-// waves 0-3 stream four rows of generation g (`rp`, with the masks the previous launch made),
-// waves 4-7 make the masks of four crosses of generation g+1 (`mp`).  A workgroup's waves are
-// dealt to the CU's four SIMDs in turn, so each SIMD gets one memory-bound and one VALU-bound
-// wave per workgroup whatever the dispatcher does with workgroups.  (Giving whole workgroups
-// one role each was measured to put each role on half of the CUs only.)  The two halves never
-// meet at a barrier.
-template <int TT>
+// One launch, two roles, for rows that one wave handles.  A workgroup is 8 waves: waves 0-3
+// stream four rows of generation g (`rp`, with the masks the previous launch made), waves 4-7
+// make masks of generation g+1 (`mp`): of four crosses (MW = 1, many crosses to do), or all four
+// on one cross (MW = 4: few crosses, e.g. masks shared by all envs -- the short way keeps the
+// mask work from outlasting the streaming it hides under).  A workgroup's waves are dealt to
+// the CU's four SIMDs in turn, so each SIMD gets one memory-bound and one VALU-bound wave per
+// workgroup whatever the dispatcher does with workgroups.  (Giving whole workgroups one role
+// each was measured to put each role on half of the CUs only.)  Row and mask waves never wait
+// for each other after the barrier at entry.
+template <int TT, int MW>
 __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
+  __shared__ unsigned counter;
   const int wave = (int)(threadIdx.x >> 6);
+  if constexpr (MW == 4) {
+    if (threadIdx.x == 0) counter = 0;
+    __syncthreads();
+  }
 #if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation.sh)
   if (wave < 4) return;
 #elif defined(BH_ABLATE_NO_MASKROLE)
@@ -442,8 +462,11 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
 #endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) row_role<1, TT, MODE_CROSS>(rp, (int)blockIdx.x, wave, nullptr);
-  } else {
-    if ((int)blockIdx.x < mp.n_blocks) mask_role<1>(mp, (int)blockIdx.x, wave - 4, lds_raw);
+  } else if ((int)blockIdx.x < mp.n_blocks) {
+    if constexpr (MW == 1)
+      mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
+    else
+      mask_role<4, SYNC_COUNTER>(mp, (int)blockIdx.x, wave - 4, lds_raw, &counter);
   }
 }
 
@@ -522,6 +545,58 @@ __global__ __launch_bounds__(1024) void topk_chunk_kernel(const TopkParams p) {
       p.out_scores[o] = valid ? __uint_as_float(u) : -INFINITY;
     }
   }
+}
+
+// ---- founder draw of VecBreedGym.reset on the device ---------------------------------------
+// env e: key_e = split(env_key, E+1)[1+e]; permutation(key_e, N)[:n] by jax's `_shuffle`:
+// `rounds` times { key, sub = split(key); stable-sort the current order by random_bits(sub, N) }.
+// One workgroup per env; the sort is a bitonic sort of (random word << 32 | position) in LDS,
+// which is the stable sort because positions are unique.  N <= 8192.
+struct FoundersParams {
+  int32_t *out;  // (E, n)
+  uint32_t key0, key1;
+  int32_t E, N, n, P, rounds;
+};
+
+__global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
+  extern __shared__ __align__(16) uint64_t fk[];  // P keys, then 2 x P int32 orders
+  int32_t *x = reinterpret_cast<int32_t *>(fk + p.P), *y = x + p.P;
+  const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e));
+  for (int i = tid; i < p.N; i += nt) x[i] = i;
+  const int L = p.N + (p.N & 1), h = L >> 1;
+  for (int rd = 0; rd < p.rounds; ++rd) {
+    const u32x2 nk = split_at(k.x, k.y, 2u, 0u), sub = split_at(k.x, k.y, 2u, 1u);
+    k = nk;
+    for (int i = tid; i < h; i += nt) {  // random_bits(sub, N): odd N is padded with a 0 counter
+      const bool second = i + h < p.N;
+      const u32x2 o = threefry2x32(sub.x, sub.y, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
+      fk[i] = ((uint64_t)o.x << 32) | (uint32_t)i;
+      if (second) fk[i + h] = ((uint64_t)o.y << 32) | (uint32_t)(i + h);
+    }
+    for (int i = p.N + tid; i < p.P; i += nt) fk[i] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= p.P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int j = tid; j < (p.P >> 1); j += nt) {
+          const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1)), hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const uint64_t a = fk[lo], b = fk[hi];
+          if ((a > b) == up) {
+            fk[lo] = b;
+            fk[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < p.N; i += nt) y[i] = x[(uint32_t)fk[i]];
+    __syncthreads();
+    int32_t *t = x;
+    x = y;
+    y = t;
+  }
+  for (int i = tid; i < p.n; i += nt) p.out[(int64_t)e * p.n + i] = x[i];
 }
 
 }  // namespace bh

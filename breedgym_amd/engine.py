@@ -202,6 +202,18 @@ class HipEngine(EngineBase):
         _lib.check(self._L.bh_topk(self._h, s2.data_ptr(), s2.shape[0], s2.shape[1], int(k), out.data_ptr()))
         return out.reshape(*s.shape[:-1], int(k))
 
+    def founders(self, env_key: np.ndarray, n_envs: int, n_germplasm: int, n: int):
+        """Founder draw of ``VecBreedGym.reset`` on the device -> ((n_envs * n,) int32 tensor, new key)."""
+        k = np.ascontiguousarray(env_key, np.uint32).copy()
+        out = torch.empty((int(n_envs) * int(n),), dtype=torch.int32, device=self.device)
+        _lib.check(
+            self._L.bh_founders_device(
+                self._h, k.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(n_envs), int(n_germplasm), int(n),
+                out.data_ptr(),
+            )
+        )
+        return out, k
+
     def set_mask_prefetch(self, enable: bool) -> None:
         """Run-ahead of the next generation's crossover masks on a side stream (default on)."""
         _lib.check(self._L.bh_set_mask_prefetch(self._h, int(bool(enable))))

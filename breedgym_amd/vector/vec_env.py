@@ -182,8 +182,7 @@ class VecBreedGym(_VectorEnvBase):
 
         eng = self.simulator.engine
         E, n = self.num_envs, self.individual_per_gen
-        founders, self.random_key = rng.founders(self.random_key, E, len(self.germplasm), n)
-        idx = torch.from_numpy(founders.reshape(-1)).to(eng.device)
+        idx, self.random_key = eng.founders(self.random_key, E, len(self.germplasm), n)
         rows = eng.empty_population(E * n)
         gebv = eng.empty((E, n, eng.n_traits), torch.float32)
         eng.gather(self._germ_rows, idx, rows, gebv)

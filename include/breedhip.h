@@ -142,6 +142,11 @@ int bh_permutation(const uint32_t key[2], int64_t n, int32_t *out);
 int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
                 int32_t *out);
 
+/* The same draw made on the device (one workgroup per env: Threefry + bitonic sort in LDS),
+ * written to d_out (E, n) int32 in stream order; env_key is advanced on the host. */
+int bh_founders_device(bh_ctx *ctx, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm,
+                       int64_t n, int32_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

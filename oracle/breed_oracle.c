@@ -197,7 +197,9 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
    *   keys = split(sim_key, 2*B + 1); sim_key <- keys[0];
    *   gamete (b, p) uses keys[1 + 2*b + p];
    *   inside meiosis: rec_key = split(gamete_key, 2)[0].
-   * B = n_out when the key is shared by all envs, E*n_out otherwise. */
+   * B = n_out when the key is shared by all envs (the masks are then computed
+   * once per cross slot and applied to every env, as the reference's vmapped
+   * graph does), E*n_out otherwise. */
   if (n_pool <= 0 && E * n_out > 0) return -1;
 
   int64_t B = rng_mode == 0 ? n_out : E * n_out;
@@ -206,26 +208,30 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
   key[0] = keys[0];
   key[1] = keys[1];
 
-  int64_t row = 2 * M;
-#pragma omp parallel
-  {
-    uint8_t *mask = (uint8_t *)malloc((size_t)(M > 0 ? M : 1));
-#pragma omp for schedule(static)
-    for (int64_t c = 0; c < E * n_out; ++c) {
-      int64_t e = c / n_out, i = c % n_out;
-      int64_t b = rng_mode == 0 ? i : c;
-      for (int p = 0; p < 2; ++p) {
-        uint32_t two[4];
-        bo_split(&keys[2 * (1 + 2 * b + p)], 2, two);
-        bo_meiosis_mask(two, r, M, mask); /* two[0..1] = rec key */
-        const uint8_t *par = pool + (e * n_pool + bo_norm_index(idx[2 * c + p], n_pool)) * row;
-        uint8_t *o = out + c * row;
-        for (int64_t m = 0; m < M; ++m) o[2 * m + p] = par[2 * m + mask[m]];
-        if (masks) memcpy(masks + (2 * c + p) * M, mask, (size_t)M);
-      }
-    }
-    free(mask);
+  /* pass 1: the 2*B crossover masks */
+  uint8_t *mk = (uint8_t *)malloc((size_t)(2 * B * M > 0 ? 2 * B * M : 1));
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < 2 * B; ++g) {
+    uint32_t two[4];
+    bo_split(&keys[2 * (1 + g)], 2, two);
+    bo_meiosis_mask(two, r, M, mk + g * M); /* two[0..1] = rec key */
   }
+
+  /* pass 2: gather the parents through idx and pick the alleles the masks name */
+  int64_t row = 2 * M;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < E * n_out; ++c) {
+    int64_t e = c / n_out, i = c % n_out;
+    int64_t b = rng_mode == 0 ? i : c;
+    for (int p = 0; p < 2; ++p) {
+      const uint8_t *mask = mk + (2 * b + p) * M;
+      const uint8_t *par = pool + (e * n_pool + bo_norm_index(idx[2 * c + p], n_pool)) * row;
+      uint8_t *o = out + c * row;
+      for (int64_t m = 0; m < M; ++m) o[2 * m + p] = par[2 * m + mask[m]];
+      if (masks) memcpy(masks + (2 * c + p) * M, mask, (size_t)M);
+    }
+  }
+  free(mk);
   free(keys);
   return 0;
 }

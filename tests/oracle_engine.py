@@ -77,5 +77,9 @@ class OracleEngine(EngineBase):
         out = np.stack([co.topk(row, k) for row in s2])
         return torch.from_numpy(out.reshape(*s.shape[:-1], k))
 
+    def founders(self, env_key, n_envs, n_germplasm, n):
+        f, k = co.founders(env_key, n_envs, n_germplasm, n)
+        return torch.from_numpy(f.reshape(-1)), k
+
     def sync(self):
         pass

@@ -286,3 +286,16 @@ def test_recombination_probability_edges(M, rng):
         got, key, _ = run_cross(eng, pool, idx, 17, mode)
         ref, refkey = co.cross(pool, idx, r, co.key_from_seed(17), mode)
         assert np.array_equal(got, ref) and np.array_equal(key, refkey)
+
+
+@pytest.mark.parametrize("N,n,E", [(1, 1, 1), (2, 2, 3), (370, 200, 4), (370, 370, 16), (1000, 10, 2), (1625, 64, 2),
+                                     (1626, 64, 2), (5000, 4999, 2), (8192, 100, 3), (8193, 50, 2)])
+def test_founder_draw_on_device(N, n, E):
+    """the reset founder draw (jax.random.choice without replacement per env) == oracle, incl. the
+    two-round shuffle (N > 1625) and the host fallback (N > 8192)"""
+    eng = make_engine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32))
+    for seed in (7, 12345):
+        got, key = eng.founders(co.key_from_seed(seed), E, N, n)
+        ref, refkey = co.founders(co.key_from_seed(seed), E, N, n)
+        assert np.array_equal(got.cpu().numpy().reshape(E, n), ref), (N, n, E)
+        assert np.array_equal(key, refkey)
