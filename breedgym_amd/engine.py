@@ -41,6 +41,25 @@ class DeviceArray(torch.Tensor):
         return self
 
 
+def _numpy_style(name):
+    """``np.max(x, axis=(1, 2))`` calls ``x.max(axis=..., out=None)``: answer NumPy-style calls in
+    NumPy (on the host copy), leave torch-style calls (``dim=``, positional) to torch."""
+    torch_fn = getattr(torch.Tensor, name)
+
+    def method(self, *args, **kwargs):
+        if "axis" in kwargs or "out" in kwargs or "keepdims" in kwargs:
+            kwargs.pop("out", None)
+            return getattr(np.asarray(self), name)(*args, **kwargs)
+        return torch_fn(self, *args, **kwargs)
+
+    method.__name__ = name
+    return method
+
+
+for _name in ("max", "min", "sum", "mean", "std", "var", "argmax", "argmin", "any", "all", "prod"):
+    setattr(DeviceArray, _name, _numpy_style(_name))
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 

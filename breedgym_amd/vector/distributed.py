@@ -1,0 +1,162 @@
+"""Multi-GPU: one process per GPU, ``torch.distributed`` (RCCL over xGMI on MI355X, gloo on CPU).
+
+Two ways the hot path shards:
+
+* **env-sharded** -- ``DistributedBreedGym``.  The role of the reference's
+  ``DistributedBreedGym`` (``vec_env.py:150-236``: one worker process per device, observations
+  piped back to a parent through Gymnasium's ``AsyncVectorEnv``).  Here every rank simply owns
+  ``envs_per_device`` envs of a ``VecBreedGym`` on its own GPU; ``step`` has no collective at
+  all, observations never leave the device, and only what a learner on another rank needs
+  (rewards, GEBV) is all-gathered on request -- 4 B per env, 4 B x n x T per env.
+* **population-sharded** -- ``ShardedPopulation``.  One large population (BASELINE config 4:
+  65,536 individuals x 100k markers) split row-wise over the ranks.  Per generation:
+  local GEBV -> local top-k -> all-gather of (score, global index) candidates (8 B x k per rank)
+  -> every rank computes the same global top-k -> all-gather of the selected parents' genotype
+  rows (each rank contributes the winners it owns) -> each rank crosses its own shard of the
+  next generation from the replicated parent pool.  Top-k is not an element-wise reduce-op, so
+  BASELINE's "all-reduce" is an all-gather plus an identical local selection on every rank; the
+  scalar best-GEBV reward is a real MAX all-reduce.
+
+Nothing here launches kernels of its own: compute goes through the engine of the wrapped env.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..engine import DeviceArray
+from .vec_env import VecBreedGym
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class DistributedBreedGym:
+    """``num_envs = envs_per_device * world_size`` breeding programmes, ``envs_per_device`` per rank."""
+
+    def __init__(self, envs_per_device: int, initial_population, group=None, **kwargs):
+        self.group = group
+        self.rank, self.world_size = _world(group)
+        self.envs_per_device = envs_per_device
+        self.num_envs = envs_per_device * self.world_size
+        self.env = VecBreedGym(num_envs=envs_per_device, initial_population=initial_population, **kwargs)
+        self.device = self.env.device
+
+    # the slice of a global (num_envs, ...) array this rank owns
+    def local_slice(self) -> slice:
+        return slice(self.rank * self.envs_per_device, (self.rank + 1) * self.envs_per_device)
+
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+        # decorrelate the ranks' founder draws and crossover streams: rank r uses seed + r
+        return self.env.reset(seed=None if seed is None else seed + self.rank, options=options)
+
+    def step(self, actions):
+        """`actions`: this rank's (envs_per_device, n, 2) slice, or the global (num_envs, n, 2) array."""
+        if actions.shape[0] == self.num_envs and self.world_size > 1:
+            actions = actions[self.local_slice()]
+        return self.env.step(actions)
+
+    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        """(envs_per_device, ...) on every rank -> (num_envs, ...) on every rank."""
+        t = local.as_subclass(torch.Tensor).contiguous()
+        if self.world_size == 1:
+            return t
+        out = torch.empty((self.world_size, *t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group) if t.is_cuda else dist.all_gather(
+            list(out.unbind(0)), t, group=self.group
+        )
+        return out.reshape(self.num_envs, *t.shape[1:])
+
+    def gather_rewards(self, local_rewards) -> np.ndarray:
+        t = local_rewards if isinstance(local_rewards, torch.Tensor) else torch.as_tensor(np.asarray(local_rewards))
+        t = t.to(device=self.device, dtype=torch.float32)
+        return self.all_gather(t).cpu().numpy()
+
+    def best_reward(self, local_rewards) -> float:
+        """max over all envs of all ranks: a MAX all-reduce of one float."""
+        t = local_rewards if isinstance(local_rewards, torch.Tensor) else torch.as_tensor(np.asarray(local_rewards))
+        m = t.to(device=self.device, dtype=torch.float32).as_subclass(torch.Tensor).max().reshape(1)
+        if self.world_size > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        return float(m.item())
+
+    def close(self):
+        self.env.close()
+
+
+class ShardedPopulation:
+    """One population of ``n_total`` individuals, rows ``[rank * n_local, (rank + 1) * n_local)`` here."""
+
+    def __init__(self, simulator, local_rows: torch.Tensor, group=None):
+        self.sim = simulator
+        self.eng = simulator.engine
+        self.group = group
+        self.rank, self.world_size = _world(group)
+        self.rows = local_rows  # (n_local, pitch) uint8 on this rank's device
+        self.n_local = local_rows.shape[0]
+        self.n_total = self.n_local * self.world_size
+
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size == 1:
+            return t.unsqueeze(0)
+        out = torch.empty((self.world_size, *t.shape), dtype=t.dtype, device=t.device)
+        if t.is_cuda:
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        else:
+            dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
+        return out
+
+    def gebv(self) -> torch.Tensor:
+        return self.eng.gebv(self.rows)
+
+    def global_topk(self, local_scores: torch.Tensor, k: int) -> torch.Tensor:
+        """Global indices (descending score, ties to the lower global index) of the k best of the
+        whole population, identical on every rank.  Candidates: each rank's local top-min(k, n_local)."""
+        s = local_scores.as_subclass(torch.Tensor).reshape(-1).to(torch.float32)
+        kk = min(k, self.n_local)
+        loc = self.eng.topk(s, kk).to(torch.int64)
+        cand_s = self._all_gather(s[loc])  # (W, kk)
+        cand_i = self._all_gather(loc + self.rank * self.n_local)  # (W, kk) global indices
+        # same order as jax.lax.top_k on the concatenated scores: the candidates arrive sorted per
+        # rank, ranks own ascending index ranges, so a top-k over the flat candidate list with ties
+        # to the earlier position is a top-k with ties to the lower global index
+        flat_s, flat_i = cand_s.reshape(-1), cand_i.reshape(-1)
+        order = torch.argsort(flat_i)  # candidate list in global-index order
+        best = self.eng.topk(flat_s[order], k).to(torch.int64)
+        return flat_i[order][best]
+
+    def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
+        """The genotype rows of `global_idx` (k,), replicated on every rank: each rank contributes the
+        rows it owns (padded to k so that one all-gather moves them), the rest is selected locally."""
+        k = global_idx.numel()
+        owner = torch.div(global_idx, self.n_local, rounding_mode="floor")
+        mine = owner == self.rank
+        local_idx = (global_idx - self.rank * self.n_local)[mine].to(torch.int32)
+        send = torch.zeros((k, self.rows.shape[1]), dtype=torch.uint8, device=self.rows.device)
+        if local_idx.numel():
+            self.eng.gather(self.rows, local_idx.contiguous(), send)
+        allrows = self._all_gather(send)  # (W, k, pitch)
+        counts = self._all_gather(mine.sum().reshape(1)).reshape(-1)  # winners per rank
+        # position of winner j inside its owner's block = its rank among that owner's winners
+        pos = torch.zeros(k, dtype=torch.int64, device=global_idx.device)
+        for r in range(self.world_size):
+            m = owner == r
+            pos[m] = torch.arange(int(counts[r]), device=global_idx.device)
+        return allrows[owner, pos]
+
+    def select_and_cross(self, k: int, pairs_local: torch.Tensor, key: np.ndarray) -> DeviceArray:
+        """One generation: global top-k by GEBV (first trait), replicate the winners, cross this rank's
+        shard of the next generation.  `pairs_local` (n_local, 2) int32 indexes the k winners."""
+        scores = self.gebv()[:, 0]
+        best = self.global_topk(scores, k)
+        parents = self.gather_rows(best)
+        out = self.eng.empty_population(self.n_local)
+        gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
+        idx = pairs_local.reshape(1, -1, 2).to(device=self.eng.device, dtype=torch.int32).contiguous()
+        self.eng.cross(parents.contiguous(), 1, k, idx, self.n_local, key, 1, out, gebv)
+        self.rows = out
+        return DeviceArray.wrap(gebv)

@@ -1,0 +1,128 @@
+"""CPU: the N > 1 paths under gloo with world_size 2 (one process per "GPU"; the engine is the
+oracle-backed test double).  Env-sharded stepping has no collective; the population-sharded
+generation uses all-gathers for top-k candidates and selected parents."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+M, N = 96, 40
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(rank, world, port):
+    for p in (str(ROOT), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _env_sharded_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    from oracle_engine import OracleEngine
+
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector.distributed import DistributedBreedGym
+    from oracle import c_oracle as co
+
+    gm = synthetic_genetic_map(M, n_chr=2, seed=1)
+    geno = synthetic_genotypes(N, M, seed=2)
+    env = DistributedBreedGym(3, geno, individual_per_gen=8, genetic_map=gm, reward_shaping=True,
+                              engine=OracleEngine(gm.recombination_vec, gm.marker_effects))
+    assert env.num_envs == 3 * world and env.local_slice() == slice(3 * rank, 3 * rank + 3)
+    pop, _ = env.reset(seed=10)
+    global_actions = np.random.default_rng(0).integers(0, 8, (3 * world, 8, 2), dtype=np.int32)
+    new_pop, r, ter, tru, infos = env.step(global_actions)  # takes its own slice
+    # what this rank must have computed: seed 10 + rank, its slice of the actions
+    f, _ = co.founders(co.key_from_seed(10 + rank), 3, N, 8)
+    ref, _ = co.cross(geno.view(np.uint8)[f], global_actions[env.local_slice()], gm.recombination_vec,
+                      co.key_from_seed(10 + rank), 0)
+    assert np.array_equal(np.asarray(new_pop).view(np.uint8), ref)
+    allr = env.gather_rewards(r)
+    assert allr.shape == (3 * world,) and np.allclose(allr[env.local_slice()], r)
+    best = env.best_reward(r)
+    assert abs(best - allr.max()) < 1e-6
+    g = env.all_gather(infos["GEBV"])
+    assert g.shape == (3 * world, 8, 1)
+    q.put((rank, allr.tolist(), best))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _pop_sharded_worker(rank, world, port, q):
+    _setup(rank, world, port)
+    from oracle_engine import OracleEngine
+
+    from breedgym_amd.simulator import Simulator
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector.distributed import ShardedPopulation
+    from oracle import c_oracle as co
+
+    gm = synthetic_genetic_map(M, n_chr=2, seed=1)
+    geno = synthetic_genotypes(N, M, seed=2).view(np.uint8)  # the whole population, known to the test only
+    n_local = N // world
+    sim = Simulator(genetic_map=gm, engine=OracleEngine(gm.recombination_vec, gm.marker_effects), seed=0)
+    rows = sim.engine.upload_population(geno[rank * n_local : (rank + 1) * n_local])
+    sp = ShardedPopulation(sim, rows)
+    scores_all = co.gebv(geno, gm.marker_effects)[:, 0]
+    scores_all[7] = scores_all[31] = scores_all[3]  # ties across shards resolve to the lower global index
+    for k in (1, 5, 13, n_local, n_local + 4):
+        got = sp.global_topk(torch.from_numpy(scores_all[rank * n_local : (rank + 1) * n_local].copy()), k)
+        assert np.array_equal(got.numpy(), co.topk(scores_all, k)), k
+    best = sp.global_topk(sp.gebv()[:, 0], 9)
+    parents = sp.gather_rows(best)
+    assert np.array_equal(parents.numpy()[:, : 2 * M].reshape(9, M, 2), geno[best.numpy()])
+    # one full generation: every rank crosses its shard from the replicated winners
+    pairs = torch.from_numpy(np.random.default_rng(rank).integers(0, 9, (n_local, 2), dtype=np.int32))
+    key = co.key_from_seed(100 + rank).copy()
+    g = sp.select_and_cross(9, pairs, key)
+    true_best = co.topk(co.gebv(geno, gm.marker_effects)[:, 0], 9)
+    ref, refkey = co.cross(geno[true_best][None], pairs.numpy()[None], gm.recombination_vec,
+                           co.key_from_seed(100 + rank), 1)
+    assert np.array_equal(sp.rows.numpy()[:, : 2 * M].reshape(n_local, M, 2), ref[0])
+    assert np.array_equal(key, refkey) and np.allclose(np.asarray(g), co.gebv(ref[0], gm.marker_effects))
+    q.put((rank, best.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(worker, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    return sorted(q.get(timeout=5) for _ in range(world))
+
+
+@pytest.mark.timeout(180)
+def test_env_sharded_two_ranks():
+    out = _run(_env_sharded_worker)
+    assert out[0][1] == out[1][1]  # every rank sees the same gathered rewards
+    assert out[0][2] == out[1][2]
+
+
+@pytest.mark.timeout(180)
+def test_population_sharded_two_ranks():
+    out = _run(_pop_sharded_worker)
+    assert out[0][1] == out[1][1]  # identical global top-k on every rank
