@@ -143,8 +143,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: breedgym_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     gm = synthetic_genetic_map(N_MARKERS, n_chr=10, n_traits=1, seed=1)
@@ -168,14 +170,14 @@ def main():
     ]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     env.reset(seed=100 + rank)
     dt = time_steps(env, actions, args.steps, args.warmup, barrier)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
     crosses_per_step = N_ENVS * N_PER_ENV
@@ -187,7 +189,7 @@ def main():
     env_i.reset(seed=100 + rank)
     dt_i = time_steps(env_i, actions, args.steps, args.warmup, barrier)
     ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(ti, op=dist.ReduceOp.MAX)
     kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
 
@@ -242,7 +244,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(gm, geno, 0)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

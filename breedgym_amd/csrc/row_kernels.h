@@ -291,6 +291,16 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   }
 }
 
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ __forceinline__ float from_orderable(uint32_t u) {
+  u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+  return __uint_as_float(u);
+}
+
 // offspring dword k of one 16-byte vector: dword k holds markers 2k, 2k+1 as bytes
 // [m0 a0, m0 a1, m1 a0, m1 a1]; output byte (marker, p) = parent p's byte (marker, mask_p).
 // zz = the vector's 16 mask bits (low byte gamete 0, high byte gamete 1).  nibble =
@@ -488,11 +498,6 @@ __global__ __launch_bounds__(256) void reward_max_kernel(const float *g, int64_t
 // key = (~orderable(score)) << 32 | index : ascending key order = descending score, ties to
 // the lower index (jax.lax.top_k).  One block sorts one chunk of up to P (power of two)
 // candidates of one row and emits its first kk (index, score) pairs.
-__device__ __forceinline__ uint32_t orderable(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-
 struct TopkParams {
   const float *scores;    // (rows, n_in) candidate scores
   const int32_t *in_idx;  // (rows, n_in) original indices, or null (= position)

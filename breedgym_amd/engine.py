@@ -182,8 +182,8 @@ class HipEngine(EngineBase):
         return out.view(np.bool_)
 
     # ---- operators ---------------------------------------------------------------------
-    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None) -> None:
-        """Fused gather + meiosis + GEBV (bh_cross).  ``key`` (uint32[2]) is advanced in place."""
+    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None) -> None:
+        """Fused gather + meiosis + GEBV (+ per-env max reward) (bh_cross).  ``key`` (uint32[2]) is advanced in place."""
         assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
         assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_envs * n_out * 2
         assert pool.shape[0] >= n_envs * pool_rows and out.shape[0] >= n_envs * n_out
@@ -192,6 +192,7 @@ class HipEngine(EngineBase):
             self._L.bh_cross(
                 self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
                 key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out.data_ptr(), _ptr(gebv),
+                _ptr(reward),
             )
         )
 

@@ -133,10 +133,11 @@ class Simulator:
 
     # ---- the hot path --------------------------------------------------------------------
     def cross_indexed(self, pool_rows_t, n_envs, pool_rows, idx, n_out, out_rows_t, gebv=None,
-                      rng_mode: int = _lib.RNG_SHARED_ENVS) -> None:
-        """Fused ``population[actions]`` + ``cross`` + ``GEBV_model``; advances ``random_key`` once."""
+                      rng_mode: int = _lib.RNG_SHARED_ENVS, reward=None) -> None:
+        """Fused ``population[actions]`` + ``cross`` + ``GEBV_model`` (+ the per-env max reward);
+        advances ``random_key`` once."""
         key = np.ascontiguousarray(self.random_key, np.uint32)
-        self.engine.cross(pool_rows_t, n_envs, pool_rows, idx, n_out, key, rng_mode, out_rows_t, gebv)
+        self.engine.cross(pool_rows_t, n_envs, pool_rows, idx, n_out, key, rng_mode, out_rows_t, gebv, reward)
         self.random_key = key
 
     def cross(self, parents) -> DeviceArray:

@@ -150,16 +150,20 @@ class VecBreedGym(_VectorEnvBase):
         E, n_pool, n_out = self.num_envs, self._n, idx.shape[1]
         out = eng.empty_population(E * n_out)
         gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
-        self.simulator.cross_indexed(self._rows, E, n_pool, idx, n_out, out, gebv, self._rng_mode)
+        done = self.step_idx + 1 == self.num_generations
+        # the reward (max GEBV per env, vec_env.py:96-98) comes out of the same launch when it is due
+        rew_dev = eng.empty((E,), torch.float32) if (self.reward_shaping or done) else None
+        self.simulator.cross_indexed(self._rows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev)
         self._adopt(out, n_out)
         self.step_idx += 1
 
         infos = {"GEBV": DeviceArray.wrap(gebv)}
-        done = self.step_idx == self.num_generations
-        if self.reward_shaping or done:
-            rews = self._rewards(gebv)
-        else:
+        if rew_dev is None:
             rews = np.zeros(self.num_envs)
+        elif self.sync_rewards:
+            rews = rew_dev.cpu().numpy()  # the reference's np.max(...) also syncs here (vec_env.py:97-98)
+        else:
+            rews = DeviceArray.wrap(rew_dev)
 
         if done and self.autoreset:
             self.reset()  # like the reference: obs is post-reset, infos pre-reset (vec_env.py:102-107)

@@ -95,12 +95,14 @@ int bh_download_population(bh_ctx *ctx, const uint8_t *d_src, int64_t rows, uint
  *                                           out of range is clamped (JAX gather rules)
  *   d_out   (n_envs, n_out, pitch) u8       offspring; out[e,i,m,p] comes from parent p
  *   d_gebv  (n_envs, n_out, T) f32 or NULL  GEBV of the offspring
+ *   d_reward (n_envs) f32 or NULL           max over an env's (n_out, T) GEBV block -- the reward of
+ *                                           vec_env.py:97 -- enqueued right behind the cross launch
  *   sim_key host, in/out                    the simulator's threefry key; advanced once
  *                                           per call like `Simulator.cross` does
  * d_out must not alias d_pool. */
 int bh_cross(bh_ctx *ctx, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows,
              const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
-             uint8_t *d_out, float *d_gebv);
+             uint8_t *d_out, float *d_gebv, float *d_reward);
 
 /* Run-ahead of the crossover masks.  The masks of a generation depend on the key chain and
  * the batch size only, never on the parents, so every bh_cross launch also makes the masks of

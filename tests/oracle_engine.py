@@ -34,7 +34,7 @@ class OracleEngine(EngineBase):
     def download_population(self, rows_t):
         return self._g(rows_t).copy().view(np.bool_)
 
-    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None):
+    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None):
         self.calls["cross"] += 1
         p = self._g(pool)[: n_envs * pool_rows].reshape(n_envs, pool_rows, self.n_markers, 2)
         o, newkey = co.cross(p, idx.numpy().reshape(n_envs, n_out, 2), self.r, key, rng_mode)
@@ -42,8 +42,10 @@ class OracleEngine(EngineBase):
         out[: n_envs * n_out] = 0
         out[: n_envs * n_out, : 2 * self.n_markers] = torch.from_numpy(o.reshape(n_envs * n_out, -1))
         if gebv is not None:
-            gebv.reshape(-1, self.n_traits)[: n_envs * n_out] = torch.from_numpy(
-                co.gebv(o.reshape(-1, self.n_markers, 2), self.effects))
+            g = co.gebv(o.reshape(-1, self.n_markers, 2), self.effects)
+            gebv.reshape(-1, self.n_traits)[: n_envs * n_out] = torch.from_numpy(g)
+            if reward is not None:
+                reward[:n_envs] = torch.from_numpy(co.reward_max(g.reshape(n_envs, -1)))
 
     def gather(self, src, idx, out, gebv=None):
         self.calls["gather"] += 1

@@ -108,6 +108,27 @@ def test_traits(T, rng):
     assert gebv_close(gg.cpu().numpy(), co.gebv(sel, eff, want64=True)[1], eff)
 
 
+@pytest.mark.parametrize("E,n_out,T,mode", [(1, 1, 1, 0), (3, 8, 2, 0), (5, 7, 1, 1), (16, 256, 1, 0), (2, 13, 9, 0),
+                                               (4, 64, 3, 1)])
+def test_reward_from_the_cross_launch(E, n_out, T, mode, rng):
+    """max GEBV per env produced by the cross launch itself: exact, and repeatable launch after launch
+    (the arrival words must come back to zero), whole-workgroup envs (n_out % 4 == 0) and ragged ones."""
+    M, NP = 520, 6
+    r = np.full(M, 0.02, np.float32)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32) - 3.0  # mostly negative GEBVs too
+    eng = make_engine(r, eff)
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    rows = eng.upload_population(pool.reshape(E * NP, M, 2))
+    key = co.key_from_seed(4).copy()
+    for rep in range(4):
+        idx = rng.integers(0, NP, (E, n_out, 2), dtype=np.int32)
+        out = eng.empty_population(E * n_out)
+        g = eng.empty((E, n_out, T), torch.float32)
+        rew = torch.full((E,), 123.0, device=eng.device)
+        eng.cross(rows, E, NP, torch.from_numpy(idx).to(eng.device), n_out, key, mode, out, g, rew)
+        assert np.array_equal(rew.cpu().numpy(), g.cpu().numpy().max(axis=(1, 2))), rep
+
+
 def test_key_chain_advances_like_oracle(rng):
     M = 200
     pool = rng.integers(0, 2, (2, 6, M, 2), dtype=np.uint8)
