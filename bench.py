@@ -226,7 +226,7 @@ def main():
                 "sharding": "envs across ranks, no data-path collective",
             },
             "roofline": {
-                "kernel": "cross_kernel<1,4> (row role: gather+select+GEBV stream; mask role: next generation's Threefry)",
+                "kernel": "cross_kernel<TT=1,MW=4,R=2> (row role: gather+select+GEBV stream, 2 rows per wave; mask role: next generation's Threefry)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,

@@ -75,36 +75,50 @@ struct bh_ctx {
 
 namespace {
 
+// waves per cross in the standalone mask kernel: long rows are split over the workgroup (LDS per
+// cross is M/4 bytes, and the Threefry trips of one cross are independent)
 int waves_for(const bh_ctx *c) { return c->M <= 16384 ? 1 : 4; }
+// waves per row in the row kernel: only a few long rows are worth four waves each
+int row_waves_for(const bh_ctx *c, int64_t n_rows) { return (c->M > 16384 && n_rows < 2048) ? 4 : 1; }
 
 size_t mask_group_lds(const bh_ctx *c) { return (size_t)(c->nwh + 1) * 32; }  // S[nwh + 1][4] u64
 
-template <int WAVES, int TT, int MODE>
-int launch_row(const bh_ctx *c, const bh::RowParams &p) {
-  hipLaunchKernelGGL((bh::row_kernel<WAVES, TT, MODE>), dim3((unsigned)p.n_blocks), dim3(256), 0, c->stream, p);
+// rows one wave streams at once (the effect vectors are loaded once per trip for all of them)
+constexpr int kRowsPerWaveCross = 2, kRowsPerWavePlain = 4;
+
+template <int WAVES, int TT, int MODE, int R>
+int launch_row(const bh_ctx *c, bh::RowParams p) {
+  const int per_block = R * 4 / WAVES;
+  p.n_blocks = (p.n_rows + per_block - 1) / per_block;
+  if (R == 2 && c->M > 16384)
+    hipLaunchKernelGGL((bh::row_kernel<WAVES, TT, MODE, R, R == 2>), dim3((unsigned)p.n_blocks), dim3(256), 0,
+                       c->stream, p);
+  else
+    hipLaunchKernelGGL((bh::row_kernel<WAVES, TT, MODE, R, false>), dim3((unsigned)p.n_blocks), dim3(256), 0,
+                       c->stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "row_kernel launch: %s", hipGetErrorString(e));
   return BH_OK;
 }
 
-template <int WAVES, int MODE>
+template <int WAVES, int MODE, int R>
 int launch_row_tt(const bh_ctx *c, const bh::RowParams &p, int tt) {
   switch (tt) {
-    case 0: return launch_row<WAVES, 0, MODE>(c, p);
-    case 1: return launch_row<WAVES, 1, MODE>(c, p);
-    case 2: return launch_row<WAVES, 2, MODE>(c, p);
-    case 4: return launch_row<WAVES, 4, MODE>(c, p);
-    default: return launch_row<WAVES, 8, MODE>(c, p);
+    case 0: return launch_row<WAVES, 0, MODE, R>(c, p);
+    case 1: return launch_row<WAVES, 1, MODE, R>(c, p);
+    case 2: return launch_row<WAVES, 2, MODE, R>(c, p);
+    case 4: return launch_row<WAVES, 4, MODE, R>(c, p);
+    default: return launch_row<WAVES, 8, MODE, R>(c, p);
   }
 }
 
 template <int MODE>
-int launch_row_mode(const bh_ctx *c, bh::RowParams p, int tt) {
-  const int waves = waves_for(c);
-  const int groups = 4 / waves;
-  p.n_blocks = (p.n_rows + groups - 1) / groups;
-  if (waves == 1) return launch_row_tt<1, MODE>(c, p, tt);
-  return launch_row_tt<4, MODE>(c, p, tt);
+int launch_row_mode(const bh_ctx *c, const bh::RowParams &p, int tt) {
+  if (row_waves_for(c, p.n_rows) == 4) return launch_row_tt<4, MODE, 1>(c, p, tt);
+  // few rows: fewer per wave keeps more waves in flight
+  if (p.n_rows < 4096) return launch_row_tt<1, MODE, 1>(c, p, tt);
+  if (MODE == bh::MODE_CROSS || p.n_rows < 16384) return launch_row_tt<1, MODE, kRowsPerWaveCross>(c, p, tt);
+  return launch_row_tt<1, MODE, kRowsPerWavePlain>(c, p, tt);
 }
 
 // `waves` = waves per cross in the mask role (1 or 4)
@@ -156,32 +170,36 @@ int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
   return BH_OK;
 }
 
-// one launch: waves 0-3 of every workgroup stream `rp` (generation g), waves 4-7 fill `mp`
-// (generation g+1) with MW waves per cross.  Only for rows one wave handles (waves_for() == 1).
-template <int TT, int MW>
-int launch_cross_tt(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp) {
+// one launch: waves 0-3 of every workgroup stream `rp` (generation g, R rows per wave), waves 4-7
+// fill `mp` (generation g+1) with MW waves per cross.  Only for rows one wave handles.
+template <int TT, int MW, int R>
+int launch_cross_tt(bh_ctx *c, bh::RowParams rp, const bh::MaskParams &mp) {
+  rp.n_blocks = (rp.n_rows + 4 * R - 1) / (4 * R);
   const size_t lds = (size_t)mp.group_lds * (4 / MW);
   const int grid = rp.n_blocks > mp.n_blocks ? rp.n_blocks : mp.n_blocks;
-  hipLaunchKernelGGL((bh::cross_kernel<TT, MW>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
+  if (R == 2 && c->M > 16384)
+    hipLaunchKernelGGL((bh::cross_kernel<TT, MW, R, R == 2>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
+  else
+    hipLaunchKernelGGL((bh::cross_kernel<TT, MW, R, false>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "cross_kernel launch: %s", hipGetErrorString(e));
   return BH_OK;
 }
 
-template <int MW>
+template <int MW, int R>
 int launch_cross_mw(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp, int tt) {
   switch (tt) {
-    case 0: return launch_cross_tt<0, MW>(c, rp, mp);
-    case 1: return launch_cross_tt<1, MW>(c, rp, mp);
-    case 2: return launch_cross_tt<2, MW>(c, rp, mp);
-    case 4: return launch_cross_tt<4, MW>(c, rp, mp);
-    default: return launch_cross_tt<8, MW>(c, rp, mp);
+    case 0: return launch_cross_tt<0, MW, R>(c, rp, mp);
+    case 1: return launch_cross_tt<1, MW, R>(c, rp, mp);
+    case 2: return launch_cross_tt<2, MW, R>(c, rp, mp);
+    case 4: return launch_cross_tt<4, MW, R>(c, rp, mp);
+    default: return launch_cross_tt<8, MW, R>(c, rp, mp);
   }
 }
 
 // few crosses need masks (they are shared by all envs, or the batch is small): put four waves on
 // each so that the mask role is as short as the streaming beside it
-int mask_waves_for_runahead(int64_t B) { return B * 4 <= 2048 ? 4 : 1; }
+int mask_waves_for_runahead(const bh_ctx *c, int64_t B) { return (B * 4 <= 2048 || c->M > 16384) ? 4 : 1; }
 
 // make d_Z[buf] hold at least `bytes`; growing it waits for everything that may still touch it
 int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
@@ -484,17 +502,22 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
     const bool fused = d_gebv && c->T <= kMaxFusedTraits;
     p.t0 = 0;
     p.tcount = fused ? (int32_t)c->T : 0;
-    if (c->prefetch && waves_for(c) == 1) {
+    if (c->prefetch && row_waves_for(c, rows) == 1) {
       // run ahead: the next generation's masks need only the advanced key and the batch size, so
       // the same launch makes them (mask role) while it streams this generation (row role)
       if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
       p.Z = c->d_Z[buf];
-      const int mw = mask_waves_for_runahead(B);
+      const int mw = mask_waves_for_runahead(c, B);
       const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw);
-      p.n_blocks = (p.n_rows + 3) / 4;
-      if (int rc = mw == 1 ? launch_cross_mw<1>(c, p, mp, tt_for(p.tcount))
-                           : launch_cross_mw<4>(c, p, mp, tt_for(p.tcount)))
-        return rc;
+      const bool wide = p.n_rows >= 4096;  // else one row per wave: more waves in flight
+      int rc;
+      if (mw == 1)
+        rc = wide ? launch_cross_mw<1, kRowsPerWaveCross>(c, p, mp, tt_for(p.tcount))
+                  : launch_cross_mw<1, 1>(c, p, mp, tt_for(p.tcount));
+      else
+        rc = wide ? launch_cross_mw<4, kRowsPerWaveCross>(c, p, mp, tt_for(p.tcount))
+                  : launch_cross_mw<4, 1>(c, p, mp, tt_for(p.tcount));
+      if (rc) return rc;
       c->pf.valid = true;
       c->pf.buf = 1 - buf;
       c->pf.key0 = nk.x;

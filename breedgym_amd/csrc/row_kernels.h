@@ -63,7 +63,7 @@ struct RowParams {
   int32_t nvec;
   int32_t n_pool, n_out;  // rows per env in src / out (cross); n_pool = src rows (gather)
   int32_t n_rows;         // total output rows
-  int32_t n_blocks;       // grid size = ceil(n_rows / (4 / WAVES))
+  int32_t n_blocks;       // workgroups with row waves = ceil(n_rows / (R * 4 / WAVES))
   int32_t T, t0, tcount;  // GEBV row stride, first trait and trait count of this launch
   int32_t rng_shared;     // 1: mask row = env-local cross index (all envs share the masks)
 };
@@ -311,62 +311,67 @@ __device__ __forceinline__ uint32_t select_dword(uint32_t zz, int k, uint32_t aw
   return __builtin_amdgcn_perm(bw, aw, ((nib * 0x00208041u) & 0x01010101u) | 0x06020400u);
 }
 
-template <int TT>
-__device__ __forceinline__ void gebv_accumulate(double (&acc)[TT > 0 ? TT : 1], const uint4 o, const RowParams &p,
-                                                int v) {
-  if constexpr (TT > 0) {
-    // dosage of markers (2k, 2k+1) = bytes 0 and 2 of  w + (w >> 8)   (alleles are 0/1)
-    const uint32_t s0 = o.x + (o.x >> 8), s1 = o.y + (o.y >> 8);
-    const uint32_t s2 = o.z + (o.z >> 8), s3 = o.w + (o.w >> 8);
-    const double d0 = (double)(s0 & 0xffu), d1 = (double)((s0 >> 16) & 0xffu);
-    const double d2 = (double)(s1 & 0xffu), d3 = (double)((s1 >> 16) & 0xffu);
-    const double d4 = (double)(s2 & 0xffu), d5 = (double)((s2 >> 16) & 0xffu);
-    const double d6 = (double)(s3 & 0xffu), d7 = (double)((s3 >> 16) & 0xffu);
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      if (t < p.tcount) {
-        const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)t * p.effPitch + 8 * (int64_t)v);
-        const double2 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
-        double s = acc[t];
-        s = fma(d0, e0.x, s);
-        s = fma(d1, e0.y, s);
-        s = fma(d2, e1.x, s);
-        s = fma(d3, e1.y, s);
-        s = fma(d4, e2.x, s);
-        s = fma(d5, e2.y, s);
-        s = fma(d6, e3.x, s);
-        s = fma(d7, e3.y, s);
-        acc[t] = s;
-      }
-    }
-  }
+// the eight dosages (0, 1, 2) of one offspring vector as doubles: dosage of markers (2k, 2k+1) =
+// bytes 0 and 2 of  w + (w >> 8)  (alleles are 0/1)
+struct Dosage8 {
+  double d[8];
+};
+__device__ __forceinline__ Dosage8 dosages(const uint4 o) {
+  const uint32_t s0 = o.x + (o.x >> 8), s1 = o.y + (o.y >> 8);
+  const uint32_t s2 = o.z + (o.z >> 8), s3 = o.w + (o.w >> 8);
+  Dosage8 r;
+  r.d[0] = (double)(s0 & 0xffu);
+  r.d[1] = (double)((s0 >> 16) & 0xffu);
+  r.d[2] = (double)(s1 & 0xffu);
+  r.d[3] = (double)((s1 >> 16) & 0xffu);
+  r.d[4] = (double)(s2 & 0xffu);
+  r.d[5] = (double)((s2 >> 16) & 0xffu);
+  r.d[6] = (double)(s3 & 0xffu);
+  r.d[7] = (double)((s3 >> 16) & 0xffu);
+  return r;
 }
 
-template <int WAVES, int TT, int MODE>
+// A group of WAVES waves streams R consecutive rows at once: the marker-effect vector of a trip is
+// loaded once and applied to all R rows (with one row per wave the effects were 2x the genotype
+// bytes out of L2).  R > 1 only with WAVES == 1.
+// LONG rows (HBM-resident sets) want more loads in flight: two vectors per row and trip.
+template <int WAVES, int TT, int MODE, int R, bool LONG>
 __device__ __forceinline__ void row_role(const RowParams &p, const int block, const int wave, double *red) {
   static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or the whole workgroup");
+  static_assert(R == 1 || WAVES == 1, "several rows per group only for one-wave groups");
   constexpr int GROUPS = 4 / WAVES;
   constexpr int STRIDE = 64 * WAVES;
+  constexpr int NT = TT > 0 ? TT : 1;
   const int lane = threadIdx.x & 63;
   const int grp = wave / WAVES, wv = wave % WAVES;
   const int tid = wv * 64 + lane;  // thread index inside the group
   // wave-uniform by construction; readfirstlane tells the compiler, so row addressing is scalar
-  const int c = __builtin_amdgcn_readfirstlane(xcd_row(block, p.n_blocks) * GROUPS + grp);
-  if (c >= p.n_rows) return;  // only possible for WAVES == 1, whose waves never meet at a barrier
+  const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * GROUPS + grp) * R);
+  if (c0 >= p.n_rows) return;  // only possible for WAVES == 1, whose waves never meet at a barrier
 
-  const uint8_t *src0 = nullptr, *src1 = nullptr;
-  const uint16_t *Z16 = nullptr;
-  if constexpr (MODE == MODE_CROSS) {
-    const int e = c / p.n_out, i = c - e * p.n_out;
-    const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
-    const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
-    src0 = p.src + ((int64_t)e * p.n_pool + i0) * p.pitch;
-    src1 = p.src + ((int64_t)e * p.n_pool + i1) * p.pitch;
-    Z16 = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
-  } else if constexpr (MODE == MODE_GATHER) {
-    src0 = p.src + (int64_t)norm_index(p.idx[c], p.n_pool) * p.pitch;
-  } else {
-    src0 = p.src + (int64_t)c * p.pitch;
+  const uint8_t *src0[R], *src1[R];
+  const uint16_t *Z16[R];
+  uint8_t *dst[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    live[r] = c0 + r < p.n_rows;
+    const int c = live[r] ? c0 + r : c0;  // a dead slot re-reads row c0 and writes nothing
+    src1[r] = nullptr;
+    Z16[r] = nullptr;
+    if constexpr (MODE == MODE_CROSS) {
+      const int e = c / p.n_out, i = c - e * p.n_out;
+      const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
+      const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
+      src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.pitch;
+      src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.pitch;
+      Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
+    } else if constexpr (MODE == MODE_GATHER) {
+      src0[r] = p.src + (int64_t)norm_index(p.idx[c], p.n_pool) * p.pitch;
+    } else {
+      src0[r] = p.src + (int64_t)c * p.pitch;
+    }
+    dst[r] = (MODE == MODE_GEBV) ? nullptr : p.out + (int64_t)c * p.pitch;
   }
 
   // Row waves share their SIMD with a VALU-bound mask wave.  VALU issue is arbitrated by
@@ -374,63 +379,112 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
   // behind Threefry, or the memory pipes drain.
   __builtin_amdgcn_s_setprio(3);
 
-  double acc[TT > 0 ? TT : 1];
+  double acc[R][NT];
 #pragma unroll
-  for (int t = 0; t < (TT > 0 ? TT : 1); ++t) acc[t] = 0.0;
-  uint8_t *dst = (MODE == MODE_GEBV) ? nullptr : p.out + (int64_t)c * p.pitch;
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[r][t] = 0.0;
 
-  // two 16-byte vectors per lane and trip: all loads of a trip are issued before the first use
-  for (int v = tid; v < p.nvec; v += 2 * STRIDE) {
-    const int v1 = v + STRIDE;
-    const bool has1 = v1 < p.nvec;
-    const int w1 = has1 ? v1 : v;
-    const uint4 a0 = *reinterpret_cast<const uint4 *>(src0 + 16 * (int64_t)v);
-    const uint4 a1 = *reinterpret_cast<const uint4 *>(src0 + 16 * (int64_t)w1);
-    uint4 o0 = a0, o1 = a1;
-    if constexpr (MODE == MODE_CROSS) {
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(src1 + 16 * (int64_t)v);
-      const uint4 b1 = *reinterpret_cast<const uint4 *>(src1 + 16 * (int64_t)w1);
-      const uint32_t z0 = Z16[v], z1 = Z16[w1];
-      o0.x = select_dword(z0, 0, a0.x, b0.x);
-      o0.y = select_dword(z0, 1, a0.y, b0.y);
-      o0.z = select_dword(z0, 2, a0.z, b0.z);
-      o0.w = select_dword(z0, 3, a0.w, b0.w);
-      o1.x = select_dword(z1, 0, a1.x, b1.x);
-      o1.y = select_dword(z1, 1, a1.y, b1.y);
-      o1.z = select_dword(z1, 2, a1.z, b1.z);
-      o1.w = select_dword(z1, 3, a1.w, b1.w);
+  // VPT 16-byte vectors per lane and trip for each of the R rows; all genotype loads of a trip
+  // are issued before the first use
+  constexpr int VPT = (R == 1 || (R == 2 && LONG)) ? 2 : 1;
+  for (int v = tid; v < p.nvec; v += VPT * STRIDE) {
+    int vv[VPT];
+    bool has[VPT];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+      has[u] = v + u * STRIDE < p.nvec;
+      vv[u] = has[u] ? v + u * STRIDE : v;
     }
-    if constexpr (MODE != MODE_GEBV) {
-      *reinterpret_cast<uint4 *>(dst + 16 * (int64_t)v) = o0;
-      if (has1) *reinterpret_cast<uint4 *>(dst + 16 * (int64_t)v1) = o1;
+    uint4 a[R][VPT], b[R][VPT];
+    uint32_t z[R][VPT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < VPT; ++u) {
+        a[r][u] = *reinterpret_cast<const uint4 *>(src0[r] + 16 * (int64_t)vv[u]);
+        if constexpr (MODE == MODE_CROSS) {
+          b[r][u] = *reinterpret_cast<const uint4 *>(src1[r] + 16 * (int64_t)vv[u]);
+          z[r][u] = Z16[r][vv[u]];
+        }
+      }
+    uint4 oo[R][VPT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < VPT; ++u) {
+        uint4 o = a[r][u];
+        if constexpr (MODE == MODE_CROSS) {
+          o.x = select_dword(z[r][u], 0, a[r][u].x, b[r][u].x);
+          o.y = select_dword(z[r][u], 1, a[r][u].y, b[r][u].y);
+          o.z = select_dword(z[r][u], 2, a[r][u].z, b[r][u].z);
+          o.w = select_dword(z[r][u], 3, a[r][u].w, b[r][u].w);
+        }
+        if constexpr (MODE != MODE_GEBV) {
+          if (live[r] && has[u]) *reinterpret_cast<uint4 *>(dst[r] + 16 * (int64_t)vv[u]) = o;
+        }
+        oo[r][u] = o;
+      }
+    if constexpr (TT > 0) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        if (t < p.tcount) {
+#pragma unroll
+          for (int u = 0; u < VPT; ++u) {
+            if (has[u]) {
+              const double2 *ep =
+                  reinterpret_cast<const double2 *>(p.eff + (int64_t)t * p.effPitch + 8 * (int64_t)vv[u]);
+              const double2 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                const Dosage8 d = dosages(oo[r][u]);
+                double s = acc[r][t];
+                s = fma(d.d[0], e0.x, s);
+                s = fma(d.d[1], e0.y, s);
+                s = fma(d.d[2], e1.x, s);
+                s = fma(d.d[3], e1.y, s);
+                s = fma(d.d[4], e2.x, s);
+                s = fma(d.d[5], e2.y, s);
+                s = fma(d.d[6], e3.x, s);
+                s = fma(d.d[7], e3.y, s);
+                acc[r][t] = s;
+              }
+            }
+          }
+        }
+      }
     }
-    gebv_accumulate<TT>(acc, o0, p, v);
-    if (has1) gebv_accumulate<TT>(acc, o1, p, v1);
   }
 
   if constexpr (TT > 0) {
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      double s = acc[t];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      acc[t] = s;
-    }
+      for (int t = 0; t < TT; ++t) {
+        double s = acc[r][t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        acc[r][t] = s;
+      }
     if constexpr (WAVES > 1) {
       if (lane == 0)
-        for (int t = 0; t < TT; ++t) red[wv * TT + t] = acc[t];
+        for (int t = 0; t < TT; ++t) red[wv * TT + t] = acc[0][t];
       __syncthreads();
       if (tid == 0)
         for (int t = 0; t < TT; ++t) {
           double s = 0.0;
           for (int w = 0; w < WAVES; ++w) s += red[w * TT + t];
-          acc[t] = s;
+          acc[0][t] = s;
         }
     }
     if (tid == 0) {
 #pragma unroll
-      for (int t = 0; t < TT; ++t)
-        if (t < p.tcount) p.gebv[(int64_t)c * p.T + p.t0 + t] = (float)acc[t];
+      for (int r = 0; r < R; ++r)
+        if (live[r]) {
+#pragma unroll
+          for (int t = 0; t < TT; ++t)
+            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
+        }
     }
   }
 }
@@ -441,10 +495,10 @@ __global__ __launch_bounds__(256) void mask_kernel(const MaskParams p) {
   mask_role<WAVES, WAVES == 1 ? SYNC_WAVE : SYNC_BLOCK>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), lds_raw, nullptr);
 }
 
-template <int WAVES, int TT, int MODE>
+template <int WAVES, int TT, int MODE, int R, bool LONG>
 __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
   __shared__ double red[4 * (TT > 0 ? TT : 1)];
-  row_role<WAVES, TT, MODE>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), red);
+  row_role<WAVES, TT, MODE, R, LONG>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), red);
 }
 
 // One launch, two roles, for rows that one wave handles.  A workgroup is 8 waves: waves 0-3
@@ -456,7 +510,7 @@ __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
 // workgroup whatever the dispatcher does with workgroups.  (Giving whole workgroups one role
 // each was measured to put each role on half of the CUs only.)  Row and mask waves never wait
 // for each other after the barrier at entry.
-template <int TT, int MW>
+template <int TT, int MW, int R, bool LONG>
 __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter;
@@ -471,7 +525,7 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
   if (wave >= 4) return;
 #endif
   if (wave < 4) {
-    if ((int)blockIdx.x < rp.n_blocks) row_role<1, TT, MODE_CROSS>(rp, (int)blockIdx.x, wave, nullptr);
+    if ((int)blockIdx.x < rp.n_blocks) row_role<1, TT, MODE_CROSS, R, LONG>(rp, (int)blockIdx.x, wave, nullptr);
   } else if ((int)blockIdx.x < mp.n_blocks) {
     if constexpr (MW == 1)
       mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);

@@ -320,3 +320,35 @@ def test_founder_draw_on_device(N, n, E):
         ref, refkey = co.founders(co.key_from_seed(seed), E, N, n)
         assert np.array_equal(got.cpu().numpy().reshape(E, n), ref), (N, n, E)
         assert np.array_equal(key, refkey)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_many_rows_multi_row_waves(mode, rng):
+    """enough rows that a wave streams several at once (2 per wave for crosses, 4 for gather / GEBV),
+    with row counts that leave ragged last waves"""
+    M, T = 136, 3
+    r = (rng.random(M) * 0.05).astype(np.float32)
+    r[0] = 0.5
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eng = make_engine(r, eff)
+    E, NP, NO = 3, 50, 1367  # 4101 crosses
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    idx = rng.integers(0, NP, (E, NO, 2), dtype=np.int32)
+    for prefetch in (True, False):
+        eng.set_mask_prefetch(prefetch)
+        for rep in range(2):  # second call is a run-ahead hit
+            got, key, g = run_cross(eng, pool, idx, 5 + rep, mode)
+            ref, refkey = co.cross(pool, idx, r, co.key_from_seed(5 + rep), mode)
+            assert np.array_equal(got, ref) and np.array_equal(key, refkey)
+            assert gebv_close(g, co.gebv(ref, eff, want64=True)[1], eff)
+    # gather + GEBV and standalone GEBV with 4 rows per wave, ragged
+    src = rng.integers(0, 2, (300, M, 2), dtype=np.uint8)
+    rows = eng.upload_population(src)
+    gi = rng.integers(-300, 302, 8195).astype(np.int32)
+    out = eng.empty_population(len(gi))
+    gg = eng.empty((len(gi), T), torch.float32)
+    eng.gather(rows, torch.from_numpy(gi).to(eng.device), out, gg)
+    sel = src[np.clip(np.where(gi < 0, gi + 300, gi), 0, 299)]
+    assert np.array_equal(eng.download_population(out).view(np.uint8), sel)
+    assert gebv_close(gg.cpu().numpy(), co.gebv(sel, eff, want64=True)[1], eff)
+    assert gebv_close(eng.gebv(out).cpu().numpy(), co.gebv(sel, eff, want64=True)[1], eff)
