@@ -12,7 +12,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 LIB_PATH = _PKG / "libbreedhip.so"
-_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "threefry.h")] + [
+_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "select_kernels.h", "threefry.h")] + [
     _ROOT / "include" / "breedhip.h"
 ]
 
@@ -86,6 +86,7 @@ SIGNATURES = {
     "bh_gebv": (_int, [_vp, _vp, _i64, _vp]),
     "bh_reward_max": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "bh_topk": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "bh_selection_actions": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _u32p, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
     "bh_key_split": (_int, [_u32p, _i64, _u32p]),
     "bh_permutation": (_int, [_u32p, _i64, _i32p]),

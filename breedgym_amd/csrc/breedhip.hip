@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "row_kernels.h"
+#include "select_kernels.h"
 #include "threefry.h"
 
 namespace {
@@ -652,6 +653,51 @@ int bh_topk(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t
     n_in = chunks * kk;
     flip ^= 1;
   }
+  return BH_OK;
+}
+
+int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n, int64_t k, int64_t n_crosses,
+                         uint32_t env_key[2], int32_t *d_actions) {
+  if (int rc = check_ctx(c)) return rc;
+  if (!env_key || n_envs < 0 || n <= 0) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: bad sizes");
+  const int64_t n_pairs = k * (k - 1) / 2;
+  if (k < 2 || k > n) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 2 <= k <= n");
+  if (n_crosses < 1 || n_crosses > n_pairs || n_crosses > n)
+    return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 1 <= n_crosses <= min(k(k-1)/2, n)");
+  if (n > 8192 || n_pairs > 8192 || n_envs > 65535)
+    return fail(BH_ERR_UNSUPPORTED, "bh_selection_actions: n and k(k-1)/2 must be <= 8192");
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u);
+  if (n_envs > 0) {
+    if (!d_scores || !d_actions) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: null device pointer");
+    bh::SelectionParams p{};
+    p.scores = d_scores;
+    p.actions = d_actions;
+    p.key0 = env_key[0];
+    p.key1 = env_key[1];
+    p.E = (int32_t)n_envs;
+    p.n = (int32_t)n;
+    p.k = (int32_t)k;
+    p.n_crosses = (int32_t)n_crosses;
+    p.n_offspring = (int32_t)((n + n_crosses - 1) / n_crosses);
+    p.n_pairs = (int32_t)n_pairs;
+    p.P_top = 2;
+    while (p.P_top < n) p.P_top <<= 1;
+    p.P_pairs = 2;
+    while (p.P_pairs < n_pairs) p.P_pairs <<= 1;
+    p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_pairs)) / std::log(4294967295.0));
+    const int PK = std::max(p.P_top, p.P_pairs);
+    const size_t lds = (size_t)PK * 8 + (size_t)p.P_pairs * 8 + (size_t)k * 4;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::selection_actions_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(selection LDS): %s", hipGetErrorString(e));
+    }
+    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, PK / 2));
+    hipLaunchKernelGGL(bh::selection_actions_kernel, dim3((unsigned)n_envs), dim3(threads), lds, c->stream, p);
+    BH_HIP(hipGetLastError());
+  }
+  env_key[0] = nk.x;
+  env_key[1] = nk.y;
   return BH_OK;
 }
 

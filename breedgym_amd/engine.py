@@ -234,6 +234,21 @@ class HipEngine(EngineBase):
         )
         return out, k
 
+    def selection_actions(self, scores, k: int, n_crosses: int, env_key: np.ndarray):
+        """``SelectionScores._convert_actions`` for every env in one launch -> ((E, n, 2) int32, new key)."""
+        s = scores.as_subclass(torch.Tensor) if isinstance(scores, torch.Tensor) else torch.as_tensor(np.asarray(scores))
+        s = s.to(device=self.device, dtype=torch.float32).contiguous()
+        E, n = s.shape
+        key = np.ascontiguousarray(env_key, np.uint32).copy()
+        out = torch.empty((E, n, 2), dtype=torch.int32, device=self.device)
+        _lib.check(
+            self._L.bh_selection_actions(
+                self._h, s.data_ptr(), E, n, int(k), int(n_crosses),
+                key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), out.data_ptr(),
+            )
+        )
+        return out, key
+
     def set_mask_prefetch(self, enable: bool) -> None:
         """Run-ahead of the next generation's crossover masks on a side stream (default on)."""
         _lib.check(self._L.bh_set_mask_prefetch(self._h, int(bool(enable))))

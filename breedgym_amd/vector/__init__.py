@@ -1,3 +1,4 @@
 from .vec_env import VecBreedGym
+from .vec_wrappers import PairScores, RavelIndex, SelectionScores
 
-__all__ = ["VecBreedGym"]
+__all__ = ["VecBreedGym", "SelectionScores", "PairScores", "RavelIndex"]

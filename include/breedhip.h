@@ -132,6 +132,14 @@ int bh_reward_max(bh_ctx *ctx, const float *d_gebv, int64_t n_envs, int64_t per_
 int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64_t k,
             int32_t *d_idx_out);
 
+/* `SelectionScores._convert_actions` (vec_wrappers.py:61-79) for all envs in one launch: per env the
+ * k best by score, a random subset of n_crosses of their k(k-1)/2 diallel pairs (without
+ * replacement, key = split(env_key, E+1)[1+e]), each repeated ceil(n / n_crosses) times and cut to
+ * n.  d_scores (E, n) f32 -> d_actions (E, n, 2) int32; env_key is advanced like the wrapper's
+ * `random_key` (keys[0]).  n <= 8192 and k(k-1)/2 <= 8192. */
+int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
+                         int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
+
 /* ---- host-side RNG plumbing (JAX threefry key chains) -------------------------------- */
 /* jax.random.key(seed) (vec_env.py:115, Simulator.set_seed). */
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]);

@@ -262,6 +262,37 @@ void bo_reward_max(const float *gebv, int64_t E, int64_t nT, float *out) {
   }
 }
 
+void bo_selection_actions(const float *scores, int64_t E, int64_t n, int64_t k,
+                          int64_t n_crosses, uint32_t env_key[2], int32_t *out) {
+  int64_t P = k * (k - 1) / 2, n_off = (n + n_crosses - 1) / n_crosses;
+  uint32_t *keys = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)(E + 1));
+  int32_t *best = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
+  int32_t *pairs = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(P > 0 ? P : 1));
+  int32_t *perm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1));
+  bo_split(env_key, E + 1, keys);
+  env_key[0] = keys[0];
+  env_key[1] = keys[1];
+  for (int64_t e = 0; e < E; ++e) {
+    bo_topk(scores + e * n, n, k, best);
+    int64_t t = 0;
+    for (int64_t i = 0; i < k; ++i)
+      for (int64_t j = i + 1; j < k; ++j, ++t) {
+        pairs[2 * t] = best[i];
+        pairs[2 * t + 1] = best[j];
+      }
+    bo_permutation(&keys[2 * (e + 1)], P, perm);
+    for (int64_t s = 0; s < n; ++s) {
+      int32_t q = perm[s / n_off];
+      out[(e * n + s) * 2] = pairs[2 * q];
+      out[(e * n + s) * 2 + 1] = pairs[2 * q + 1];
+    }
+  }
+  free(keys);
+  free(best);
+  free(pairs);
+  free(perm);
+}
+
 int bo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

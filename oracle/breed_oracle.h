@@ -100,6 +100,14 @@ void bo_founders(uint32_t env_key[2], int64_t E, int64_t N, int64_t n,
 /* jax.lax.top_k indices: k largest, descending, ties -> lower index first. */
 void bo_topk(const float *scores, int64_t n, int64_t k, int32_t *out);
 
+/* SelectionScores._convert_actions for E envs (vec_wrappers.py:61-85): keys =
+ * split(env_key, E+1); env_key <- keys[0]; env e: best = topk(scores[e], k);
+ * pairs = all (best[i], best[j]), i < j, row-major; pick =
+ * permutation(keys[1+e], len(pairs))[:n_crosses]; out = repeat(pairs[pick],
+ * ceil(n / n_crosses), total_repeat_length = n).  out (E, n, 2) int32. */
+void bo_selection_actions(const float *scores, int64_t E, int64_t n, int64_t k,
+                          int64_t n_crosses, uint32_t env_key[2], int32_t *out);
+
 /* number of OpenMP threads the batch functions will use */
 int bo_num_threads(void);
 void bo_set_num_threads(int n);

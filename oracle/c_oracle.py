@@ -175,6 +175,15 @@ def topk(scores, k: int) -> np.ndarray:
     return out
 
 
+def selection_actions(scores, k: int, n_crosses: int, env_key):
+    s = np.ascontiguousarray(scores, np.float32)
+    E, n = s.shape
+    key = _key(env_key)
+    out = np.empty((E, n, 2), np.int32)
+    lib().bo_selection_actions(_p(s, _f32p), c_i64(E), c_i64(n), c_i64(k), c_i64(n_crosses), _p(key, _u32p), _p(out, _i32p))
+    return out, key
+
+
 def num_threads() -> int:
     return lib().bo_num_threads()
 

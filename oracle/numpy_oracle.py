@@ -143,6 +143,23 @@ def topk(scores, k):
     return np.argsort(-np.asarray(scores, np.float32), kind="stable")[:k].astype(np.int32)
 
 
+def selection_actions(scores, k, n_crosses, env_key):
+    """SelectionScores._convert_actions vmapped over envs + the key split of SelectionScores.step
+    (vec_wrappers.py:61-85)."""
+    scores = np.asarray(scores, np.float32)
+    E, n = scores.shape
+    keys = split(env_key, E + 1)
+    n_off = math.ceil(n / n_crosses)
+    out = np.empty((E, n, 2), np.int32)
+    for e in range(E):
+        best = topk(scores[e], k)
+        iu = np.triu_indices(k, k=1)
+        diallel = np.stack((best[iu[0]], best[iu[1]]), axis=1)
+        pick = permutation(keys[1 + e], len(diallel))[:n_crosses]
+        out[e] = np.repeat(diallel[pick], n_off, axis=0)[:n]
+    return out, keys[0].copy()
+
+
 # ---- fully vectorised variant used as the "B1" CPU baseline ------------------------------
 
 

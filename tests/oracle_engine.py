@@ -83,5 +83,10 @@ class OracleEngine(EngineBase):
         f, k = co.founders(env_key, n_envs, n_germplasm, n)
         return torch.from_numpy(f.reshape(-1)), k
 
+    def selection_actions(self, scores, k, n_crosses, env_key):
+        s = scores.as_subclass(torch.Tensor).to(torch.float32).numpy() if isinstance(scores, torch.Tensor) else np.asarray(scores, np.float32)
+        a, key = co.selection_actions(s, k, n_crosses, env_key)
+        return torch.from_numpy(a), key
+
     def sync(self):
         pass

@@ -352,3 +352,46 @@ def test_many_rows_multi_row_waves(mode, rng):
     assert np.array_equal(eng.download_population(out).view(np.uint8), sel)
     assert gebv_close(gg.cpu().numpy(), co.gebv(sel, eff, want64=True)[1], eff)
     assert gebv_close(eng.gebv(out).cpu().numpy(), co.gebv(sel, eff, want64=True)[1], eff)
+
+
+@pytest.mark.parametrize("E,n,k,nc", [(1, 2, 2, 1), (3, 50, 5, 7), (2, 200, 10, 45), (4, 210, 10, 20), (1, 64, 64, 64),
+                                        (2, 33, 2, 1), (16, 256, 25, 256), (2, 1000, 100, 1000), (1, 8192, 128, 8128)])
+def test_selection_actions_kernel(E, n, k, nc, rng):
+    """SelectionScores._convert_actions in one launch == oracle (top-k ties, shuffle of the pair
+    ranks incl. two rounds when k(k-1)/2 > 1625, triangular un-ranking, repeat/truncate)"""
+    eng = make_engine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32))
+    s = rng.standard_normal((E, n)).astype(np.float32)
+    if n > 8:
+        s[:, 3] = s[:, 7]
+    for seed in (5, 77):
+        got, key = eng.selection_actions(torch.from_numpy(s), k, nc, co.key_from_seed(seed))
+        ref, refkey = co.selection_actions(s, k, nc, co.key_from_seed(seed))
+        assert np.array_equal(got.cpu().numpy(), ref), (E, n, k, nc)
+        assert np.array_equal(key, refkey)
+    with pytest.raises(ValueError):
+        eng.selection_actions(torch.from_numpy(s), n + 1, 1, co.key_from_seed(1))
+
+
+def test_wrappers_on_device(rng):
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector import PairScores, SelectionScores
+
+    gm = synthetic_genetic_map(1000, n_chr=3)
+    geno = synthetic_genotypes(60, 1000)
+    env = SelectionScores(k=5, n_crosses=8, num_envs=3, initial_population=geno, individual_per_gen=24, genetic_map=gm,
+                          num_generations=3)
+    _, infos = env.reset(seed=7)
+    f, env_key = co.founders(co.key_from_seed(7), 3, 60, 24)
+    ref = geno.view(np.uint8)[f]
+    sim_key = co.key_from_seed(7)
+    for _ in range(3):
+        low, env_key = co.selection_actions(co.gebv(ref, gm.marker_effects)[..., 0], 5, 8, env_key)
+        ref, sim_key = co.cross(ref, low, gm.recombination_vec, sim_key, 0)
+        pop, rews, _, tru, infos = env.step(infos["GEBV"][..., 0])
+    assert tru.all() and np.allclose(rews, co.gebv(ref, gm.marker_effects).max(axis=(1, 2)), rtol=1e-5)
+    p = PairScores(num_envs=2, initial_population=geno, individual_per_gen=16, genetic_map=gm)
+    _, infos = p.reset(seed=1)
+    g = infos["GEBV"][..., 0].as_subclass(torch.Tensor)
+    obs, r, _, _, inf = p.step(g[:, :, None] + g[:, None, :])
+    assert obs.shape == (2, 16, 1000, 2) and inf["low_level_actions"].shape == (2, 16, 2)

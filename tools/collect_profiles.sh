@@ -9,7 +9,7 @@ set -e
 TAG=${1:-r01}
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 CMD="python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $CMD > $OUT/kt.log 2>&1
