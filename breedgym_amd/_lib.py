@@ -26,6 +26,7 @@ BH_ERR_BAD_GENOTYPE = -6
 
 RNG_SHARED_ENVS = 0
 RNG_INDEPENDENT = 1
+RNG_DOUBLE_HAPLOID = 2  # flag: one gamete per row, written to both allele slots
 
 
 class BreedHipError(RuntimeError):

@@ -65,6 +65,7 @@ struct bh_ctx {
     int buf = 0;
     uint32_t key0 = 0, key1 = 0;
     int64_t B = 0;
+    bool dh = false;
   } pf;
   int last_buf = 1;
   // top-k scratch
@@ -123,7 +124,7 @@ int launch_row_mode(const bh_ctx *c, const bh::RowParams &p, int tt) {
 }
 
 // `waves` = waves per cross in the mask role (1 or 4)
-bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, int waves) {
+bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, int waves, bool dh) {
   const int groups = 4 / waves;
   bh::MaskParams m{};
   m.Z = c->d_Z[buf];
@@ -142,7 +143,8 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
   m.group_lds = (int32_t)mask_group_lds(c);
   m.key0 = key0;
   m.key1 = key1;
-  m.nkeys = (uint32_t)(2 * B + 1);
+  m.nkeys = (uint32_t)(dh ? B + 1 : 2 * B + 1);
+  m.dh = dh;
   return m;
 }
 
@@ -156,9 +158,9 @@ int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
 }
 
 // crossover masks of B crosses keyed off `key` into d_Z[buf], in stream order (not overlapped)
-int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B) {
+int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bool dh) {
   const int waves = waves_for(c);
-  const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves);
+  const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves, dh);
   const size_t lds = (size_t)m.group_lds * (4 / waves);
   if (waves == 1) {
     hipLaunchKernelGGL(bh::mask_kernel<1>, dim3((unsigned)m.n_blocks), dim3(256), lds, c->stream, m);
@@ -456,11 +458,14 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
   if (int rc = check_ctx(c)) return rc;
   if (!sim_key) return fail(BH_ERR_BAD_ARG, "bh_cross: null sim_key");
   if (n_envs < 0 || n_out < 0 || pool_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_cross: negative size");
-  if (rng_mode != BH_RNG_SHARED_ENVS && rng_mode != BH_RNG_INDEPENDENT)
+  if (rng_mode < 0 || rng_mode > (BH_RNG_INDEPENDENT | BH_RNG_DOUBLE_HAPLOID))
     return fail(BH_ERR_BAD_ARG, "bh_cross: unknown rng_mode %d", rng_mode);
+  const bool dh = (rng_mode & BH_RNG_DOUBLE_HAPLOID) != 0;
+  const bool shared = (rng_mode & BH_RNG_INDEPENDENT) == 0;
   const int64_t rows = n_envs * n_out;
-  const int64_t B = rng_mode == BH_RNG_SHARED_ENVS ? n_out : rows;
-  if (rows > 0x3FFFFFFF || n_envs * pool_rows > 0x7FFFFFFF || 2 * (2 * B + 1) > 0xFFFFFFFFll)
+  const int64_t B = shared ? n_out : rows;
+  const int64_t nkeys = dh ? B + 1 : 2 * B + 1;
+  if (rows > 0x3FFFFFFF || n_envs * pool_rows > 0x7FFFFFFF || 2 * nkeys > 0xFFFFFFFFll)
     return fail(BH_ERR_UNSUPPORTED, "bh_cross: too many rows for 32-bit indexing");
   if (rows > 0) {
     if (!d_pool || !d_idx || !d_out) return fail(BH_ERR_BAD_ARG, "bh_cross: null device pointer");
@@ -474,19 +479,19 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
     // ---- this generation's masks: made by the previous call's launch, or made now
     const int64_t zbytes = B * 16 * c->nw;
     int buf;
-    if (c->pf.valid && c->pf.key0 == sim_key[0] && c->pf.key1 == sim_key[1] && c->pf.B == B) {
+    if (c->pf.valid && c->pf.key0 == sim_key[0] && c->pf.key1 == sim_key[1] && c->pf.B == B && c->pf.dh == dh) {
       buf = c->pf.buf;
     } else {  // not predicted: first call, new seed, new batch size
       buf = 1 - c->last_buf;
       if (int rc = ensure_z(c, buf, zbytes)) return rc;
-      if (int rc = launch_masks(c, buf, sim_key[0], sim_key[1], B)) return rc;
+      if (int rc = launch_masks(c, buf, sim_key[0], sim_key[1], B, dh)) return rc;
     }
     c->pf.valid = false;
     c->last_buf = buf;
   }
 
   // Simulator.cross: keys = split(key, 2B+1); key <- keys[0]
-  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)(2 * B + 1), 0u);
+  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)nkeys, 0u);
 
   if (rows > 0) {
     const int buf = c->last_buf;
@@ -499,7 +504,7 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
     p.n_pool = (int32_t)pool_rows;
     p.n_out = (int32_t)n_out;
     p.n_rows = (int32_t)rows;
-    p.rng_shared = rng_mode == BH_RNG_SHARED_ENVS;
+    p.rng_shared = shared;
     const bool fused = d_gebv && c->T <= kMaxFusedTraits;
     p.t0 = 0;
     p.tcount = fused ? (int32_t)c->T : 0;
@@ -509,7 +514,7 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
       if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
       p.Z = c->d_Z[buf];
       const int mw = mask_waves_for_runahead(c, B);
-      const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw);
+      const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh);
       const bool wide = p.n_rows >= 4096;  // else one row per wave: more waves in flight
       int rc;
       if (mw == 1)
@@ -524,6 +529,7 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
       c->pf.key0 = nk.x;
       c->pf.key1 = nk.y;
       c->pf.B = B;
+      c->pf.dh = dh;
     } else {
       if (int rc = launch_row_mode<bh::MODE_CROSS>(c, p, tt_for(p.tcount))) return rc;
     }

@@ -47,7 +47,8 @@ struct MaskParams {
   int32_t group_lds;  // LDS bytes per group (multiple of 16)
   uint32_t thr_bytes; // size of thrA / thrB in bytes (buffer descriptor range)
   uint32_t key0, key1;  // the call's simulator key
-  uint32_t nkeys;       // 2*B + 1 keys are split off it
+  uint32_t nkeys;       // keys split off it: 2*B + 1, or B + 1 for double haploids
+  int32_t dh;           // 1: both gametes of cross c use keys[1 + c] (one gamete, doubled)
 };
 
 struct RowParams {
@@ -160,12 +161,13 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   if (c >= p.n_rows) return;  // only possible for WAVES == 1, whose waves never meet at a barrier
   uint64_t *S = reinterpret_cast<uint64_t *>(lds_raw + (size_t)grp * p.group_lds);  // [nwh + 1][4]
 
-  // ---- gamete keys: keys = split(sim_key, nkeys); gamete (c, q) owns keys[1 + 2c + q]; its
+  // ---- gamete keys: keys = split(sim_key, nkeys); gamete (c, q) owns keys[1 + 2c + q] (double
+  //      haploid: the one gamete of c owns keys[1 + c] and fills both slots); its
   //      recombination key is split(gamete_key, 2)[0].  Lanes 0..3 carry the 4 words.
   uint32_t rk00, rk01, rk10, rk11;
   {
     const uint32_t q = (lane >> 1) & 1u, w = lane & 1u;
-    const uint32_t kidx = 1u + 2u * (uint32_t)c + q;
+    const uint32_t kidx = p.dh ? 1u + (uint32_t)c : 1u + 2u * (uint32_t)c + q;
     const uint32_t gw = iota_word_even(p.key0, p.key1, 2u * p.nkeys, 2u * kidx + w);
     const uint32_t g0 = __shfl(gw, lane & ~1), g1 = __shfl(gw, lane | 1);
     const uint32_t rw = threefry2x32(g0, g1, w, w + 2u).x;

@@ -152,6 +152,25 @@ class Simulator:
         self.cross_indexed(pool, 1, 2 * n, idx, n, out)
         return self.engine.as_genotypes(out)
 
+    def double_haploid(self, population, n_offspring: int = 1, *, rng_mode: int = _lib.RNG_SHARED_ENVS) -> DeviceArray:
+        """``Simulator.double_haploid`` (breeding_programs_env.py:39-41): every individual gives
+        `n_offspring` doubled-haploid lines -- one meiosis, the gamete on both strands.
+
+        (..., n, M, 2) -> (..., n, n_offspring, M, 2); leading axes are envs that share the keys
+        unless ``rng_mode`` says otherwise.  [EXTERNAL/UNVERIFIED] key plumbing: keys =
+        split(key, n * n_offspring + 1); key <- keys[0]; line (i, j) uses keys[1 + i * n_offspring + j]."""
+        rows, lead = self._rows_of(population)
+        n = lead[-1]
+        E = int(np.prod(lead[:-1])) if len(lead) > 1 else 1
+        eng = self.engine
+        one = torch.arange(n, dtype=torch.int32, device=eng.device).repeat_interleave(n_offspring)
+        idx = one.repeat(E).reshape(E, n * n_offspring, 1).expand(-1, -1, 2).contiguous()
+        out = eng.empty_population(E * n * n_offspring)
+        key = np.ascontiguousarray(self.random_key, np.uint32)
+        eng.cross(rows, E, n, idx, n * n_offspring, key, rng_mode | _lib.RNG_DOUBLE_HAPLOID, out, None)
+        self.random_key = key
+        return eng.as_genotypes(out, *lead[:-1], n, n_offspring)
+
     def random_crosses(self, population, n_crosses: int, n_offspring: int = 1):
         """n_crosses random pairs without replacement of pairs; each crossed n_offspring times."""
         rows, lead = self._rows_of(population)
@@ -179,11 +198,16 @@ class Simulator:
         scores = f_index(population)
         if not isinstance(scores, torch.Tensor):
             scores = torch.as_tensor(np.asarray(scores, np.float32))
-        best = self.engine.topk(scores.reshape(-1), k)
-        rows, _ = self._rows_of(population)
-        out = self.engine.empty_population(k)
-        self.engine.gather(rows, best, out)
-        return self.engine.as_genotypes(out), DeviceArray.wrap(best)
+        rows, lead = self._rows_of(population)
+        # (n, M, 2): the k best of the population.  (..., n, M, 2): the k best of every group of n
+        # (what `vmap(simulator.select)` over lines or envs gives, scripts/time_wheat.py:23-24)
+        n = lead[-1]
+        groups = int(np.prod(lead[:-1])) if len(lead) > 1 else 1
+        best = self.engine.topk(scores.as_subclass(torch.Tensor).reshape(groups, n), k)  # (groups, k)
+        flat = (best.to(torch.int64) + torch.arange(groups, device=best.device).unsqueeze(1) * n).to(torch.int32)
+        out = self.engine.empty_population(groups * k)
+        self.engine.gather(rows, flat.reshape(-1).contiguous(), out)
+        return self.engine.as_genotypes(out, *lead[:-1], k), DeviceArray.wrap(best.reshape(*lead[:-1], k))
 
     @staticmethod
     def _diallel_indices(indices):

@@ -47,7 +47,11 @@ typedef enum bh_status {
 typedef enum bh_rng_mode {
   BH_RNG_SHARED_ENVS = 0, /* every env gets the same gamete keys: what jax.vmap over the
                              un-batched simulator key does in vec_env.py:75-77       */
-  BH_RNG_INDEPENDENT = 1  /* the E*n crosses form one flat chromax cross() batch      */
+  BH_RNG_INDEPENDENT = 1, /* the E*n crosses form one flat chromax cross() batch      */
+  BH_RNG_DOUBLE_HAPLOID = 2 /* flag, OR-ed in: each row is ONE gamete of its parent written to
+                               both allele slots (`Simulator.double_haploid`,
+                               breeding_programs_env.py:39-41); keys = split(key, B + 1),
+                               row b uses keys[1 + b]; pass the same index twice in d_idx */
 } bh_rng_mode;
 
 typedef struct bh_ctx bh_ctx; /* opaque */

@@ -202,9 +202,14 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
    * graph does), E*n_out otherwise. */
   if (n_pool <= 0 && E * n_out > 0) return -1;
 
+  /* rng_mode bit 1 (value 2) = double haploid [EXTERNAL/UNVERIFIED chromax.Simulator.double_haploid]:
+   * keys = split(sim_key, B + 1); row b's single gamete uses keys[1 + b] and fills both slots. */
+  int dh = (rng_mode & 2) != 0;
+  rng_mode &= 1;
   int64_t B = rng_mode == 0 ? n_out : E * n_out;
-  uint32_t *keys = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)(2 * B + 1));
-  bo_split(key, 2 * B + 1, keys);
+  int64_t nkeys = dh ? B + 1 : 2 * B + 1;
+  uint32_t *keys = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)nkeys);
+  bo_split(key, nkeys, keys);
   key[0] = keys[0];
   key[1] = keys[1];
 
@@ -213,7 +218,7 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
 #pragma omp parallel for schedule(static)
   for (int64_t g = 0; g < 2 * B; ++g) {
     uint32_t two[4];
-    bo_split(&keys[2 * (1 + g)], 2, two);
+    bo_split(&keys[2 * (1 + (dh ? g / 2 : g))], 2, two);
     bo_meiosis_mask(two, r, M, mk + g * M); /* two[0..1] = rec key */
   }
 

@@ -170,6 +170,8 @@ def founders(env_key, E: int, N: int, n: int):
 
 def topk(scores, k: int) -> np.ndarray:
     s = np.ascontiguousarray(scores, np.float32)
+    if not 0 <= k <= len(s):
+        raise ValueError("topk: need 0 <= k <= n")
     out = np.empty(k, np.int32)
     lib().bo_topk(_p(s, _f32p), c_i64(len(s)), c_i64(k), _p(out, _i32p))
     return out
