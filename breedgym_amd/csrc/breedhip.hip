@@ -14,6 +14,7 @@
 #include <numeric>
 #include <vector>
 
+#include "gebv_mfma.h"
 #include "row_kernels.h"
 #include "select_kernels.h"
 #include "threefry.h"
@@ -68,6 +69,12 @@ struct bh_ctx {
     bool dh = false;
   } pf;
   int last_buf = 1;
+  // fixed-point marker effects for the int8-MFMA GEBV: one pack per group of <= 10 traits
+  std::vector<bh::i32x4 *> d_Bpack;
+  double *d_scale = nullptr;  // (T) 2^-s_t
+  int32_t n_chunks = 0;
+  int32_t *d_partial = nullptr;
+  int64_t partial_cap = 0;  // int32 words
   // top-k scratch
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};
@@ -230,8 +237,59 @@ bh::RowParams base_params(const bh_ctx *c) {
   return p;
 }
 
+// GEBV of rows already in memory on the matrix cores (gebv_mfma.h), all traits
+int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
+  constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
+  const int64_t n_tiles = (rows + 31) / 32, rows_pad = n_tiles * 32;
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((8192 + n_tiles - 1) / n_tiles, c->n_chunks / 6));
+  const int64_t per_slice = (c->n_chunks + slices - 1) / slices;
+  slices = (c->n_chunks + per_slice - 1) / per_slice;
+  const int64_t need = slices * rows_pad * bh::kGebvCols;
+  if (need > c->partial_cap) {
+    BH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_partial) BH_HIP(hipFree(c->d_partial));
+    c->d_partial = nullptr;
+    c->partial_cap = 0;
+    BH_HIP(hipMalloc(&c->d_partial, (size_t)need * sizeof(int32_t)));
+    c->partial_cap = need;
+  }
+  for (size_t g = 0; g < c->d_Bpack.size(); ++g) {
+    const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
+    bh::GebvMfmaParams p{};
+    p.pop = d_pop;
+    p.B = c->d_Bpack[g];
+    p.partial = c->d_partial;
+    p.pitch = c->pitch;
+    p.rows = (int32_t)rows;
+    p.rows_pad = (int32_t)rows_pad;
+    p.n_chunks = c->n_chunks;
+    p.chunks_per_slice = (int32_t)per_slice;
+    hipLaunchKernelGGL(bh::gebv_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4), (unsigned)slices), dim3(256), 0,
+                       c->stream, p);
+    BH_HIP(hipGetLastError());
+    bh::GebvFinishParams f{};
+    f.partial = c->d_partial;
+    f.scale = c->d_scale + t0;
+    f.gebv = d_gebv;
+    f.rows = (int32_t)rows;
+    f.rows_pad = (int32_t)rows_pad;
+    f.slices = (int32_t)slices;
+    f.T = (int32_t)tn;
+    f.Tstride = (int32_t)c->T;
+    f.t0 = (int32_t)t0;
+    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+// from this many traits on, the int8-MFMA GEBV pass beats GEBV fused into the row stream
+constexpr int kMfmaGebvMinTraits = 3;
+bool use_mfma_gebv(const bh_ctx *c, int64_t rows) { return c->T >= kMfmaGebvMinTraits && rows >= 32; }
+
 // GEBV of rows already in memory, for trait chunks [t_begin, T)
-int gebv_chunks(const bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
+int gebv_chunks(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
+  if (t_begin == 0 && use_mfma_gebv(c, rows)) return gebv_mfma(c, d_pop, rows, d_gebv);
   for (int t0 = t_begin; t0 < c->T; t0 += kMaxFusedTraits) {
     bh::RowParams p = base_params(c);
     p.src = d_pop;
@@ -356,6 +414,51 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
     BH_HIP_C(hipMemcpy(c->d_alwB, alwB.data(), alwB.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   BH_HIP_C(hipMemcpy(c->d_eff, eff.data(), eff.size() * sizeof(double), hipMemcpyHostToDevice));
+  // ---- fixed-point effects for the MFMA GEBV (gebv_mfma.h): 6 balanced base-256 digits of
+  //      round(eff * 2^s_t), s_t the largest shift that keeps |.| <= 2^46
+  if (n_traits > 0) {
+    constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;  // 10
+    c->n_chunks = (int32_t)((n_markers + 63) / 64);
+    std::vector<double> scale((size_t)n_traits);
+    std::vector<int> shift((size_t)n_traits);
+    for (int64_t t = 0; t < n_traits; ++t) {
+      double emax = 0.0;
+      for (int64_t m = 0; m < n_markers; ++m) emax = std::max(emax, std::fabs((double)effects[m * n_traits + t]));
+      int sft = 0;
+      if (emax > 0.0 && std::isfinite(emax)) {
+        int e2;
+        std::frexp(emax, &e2);  // emax = f * 2^e2, f in [0.5, 1)
+        sft = 46 - e2;          // emax * 2^sft < 2^46
+      }
+      shift[(size_t)t] = sft;
+      scale[(size_t)t] = std::ldexp(1.0, -sft);
+    }
+    BH_HIP_C(hipMalloc(&c->d_scale, (size_t)n_traits * sizeof(double)));
+    BH_HIP_C(hipMemcpy(c->d_scale, scale.data(), (size_t)n_traits * sizeof(double), hipMemcpyHostToDevice));
+    const int64_t packs = (n_traits + kTraitsPerPack - 1) / kTraitsPerPack;
+    std::vector<int8_t> pack((size_t)c->n_chunks * 4096);
+    for (int64_t g = 0; g < packs; ++g) {
+      std::fill(pack.begin(), pack.end(), (int8_t)0);
+      const int64_t t0 = g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, n_traits - t0);
+      for (int64_t m = 0; m < n_markers; ++m) {
+        const int64_t ch = m >> 6, w = m & 63, h = w >> 5, q = (w >> 4) & 1, j = w & 15;
+        for (int64_t t = 0; t < tn; ++t) {
+          long long fix = std::llround(std::ldexp((double)effects[m * n_traits + t0 + t], shift[(size_t)(t0 + t)]));
+          for (int d = 0; d < bh::kGebvDigits; ++d) {
+            long long dig = ((fix % 256) + 256) % 256;
+            if (dig >= 128) dig -= 256;
+            fix = (fix - dig) / 256;
+            const int64_t col = t * bh::kGebvDigits + d, nt = col >> 5, r = col & 31, lane = r + 32 * h;
+            pack[(size_t)((((ch * 2 + nt) * 2 + q) * 64 + lane) * 16 + j)] = (int8_t)dig;
+          }
+        }
+      }
+      bh::i32x4 *dB = nullptr;
+      BH_HIP_C(hipMalloc(&dB, pack.size()));
+      c->d_Bpack.push_back(dB);
+      BH_HIP_C(hipMemcpy(dB, pack.data(), pack.size(), hipMemcpyHostToDevice));
+    }
+  }
 #undef BH_HIP_C
   *out = c;
   return BH_OK;
@@ -369,6 +472,10 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
   if (c->d_alwA) (void)hipFree(c->d_alwA);
+  for (auto *b : c->d_Bpack)
+    if (b) (void)hipFree(b);
+  if (c->d_scale) (void)hipFree(c->d_scale);
+  if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
   for (int i = 0; i < 2; ++i) {
@@ -505,7 +612,7 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
     p.n_out = (int32_t)n_out;
     p.n_rows = (int32_t)rows;
     p.rng_shared = shared;
-    const bool fused = d_gebv && c->T <= kMaxFusedTraits;
+    const bool fused = d_gebv && c->T <= kMaxFusedTraits && !use_mfma_gebv(c, rows);
     p.t0 = 0;
     p.tcount = fused ? (int32_t)c->T : 0;
     if (c->prefetch && row_waves_for(c, rows) == 1) {
@@ -567,7 +674,7 @@ int bh_gather(bh_ctx *c, const uint8_t *d_src, int64_t src_rows, const int32_t *
   p.gebv = d_gebv;
   p.n_pool = (int32_t)src_rows;
   p.n_rows = (int32_t)n_rows;
-  const bool fused = d_gebv && c->T <= kMaxFusedTraits;
+  const bool fused = d_gebv && c->T <= kMaxFusedTraits && !use_mfma_gebv(c, n_rows);
   p.t0 = 0;
   p.tcount = fused ? (int32_t)c->T : 0;
   if (int rc = launch_row_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;

@@ -444,3 +444,27 @@ def test_wheat_breed_gym_on_device():
     assert p.shape == (2, 20, 2100, 2) and np.array_equal(p[..., 0], p[..., 1])
     assert np.allclose(r, np.asarray(infos["GEBV"]).max(axis=(1, 2)))
     assert np.asarray(infos["GEBV"]).max() > g0  # three rounds of truncation selection raise the best GEBV
+
+
+@pytest.mark.parametrize("rows,M,T", [(64, 64, 3), (65, 100, 8), (200, 1000, 10), (130, 999, 11), (300, 4001, 17),
+                                        (2048, 10000, 8), (64, 8, 4)])
+def test_gebv_on_matrix_cores(rows, M, T, rng):
+    """T >= 3 and >= 64 rows: GEBV as six int8 GEMMs on fixed-point effect digits (exact int32
+    accumulation).  Against the f64 oracle: within BASELINE's 1e-5, and in fact within an f32 ulp."""
+    pop = rng.integers(0, 2, (rows, M, 2), dtype=np.uint8)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eff[0, 0] = 475.0
+    eff[M // 2, 1] = -475.0
+    eff[:, 2] *= 1e-6  # a trait with tiny effects gets its own scale
+    if T > 3:
+        eff[:, 3] = 0.0  # and an all-zero trait
+    eng = make_engine(np.full(M, 0.01, np.float32), eff)
+    g = eng.gebv(eng.upload_population(pop)).cpu().numpy()
+    _, g64 = co.gebv(pop, eff, want64=True)
+    assert gebv_close(g, g64, eff)
+    ulp = np.spacing(np.abs(g64).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(g.astype(np.float64) - g64) <= 1.01 * ulp + 1e-30)
+    # the cross path hands the offspring to the same GEBV
+    idx = rng.integers(0, rows, (1, 70, 2), dtype=np.int32)
+    got, _, gc = run_cross(eng, pop[None], idx, 9, 0)
+    assert gebv_close(gc[0], co.gebv(got[0], eff, want64=True)[1], eff)

@@ -14,7 +14,7 @@ def ev_time(fn, reps=200):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps * 1e3
 
-for T in (1,):
+for T in (1, 2, 3, 4, 8):
     gm = synthetic_genetic_map(M, n_traits=T)
     eng = HipEngine(gm.recombination_vec, gm.marker_effects)
     geno = synthetic_genotypes(370, M)
