@@ -468,3 +468,56 @@ def test_gebv_on_matrix_cores(rows, M, T, rng):
     idx = rng.integers(0, rows, (1, 70, 2), dtype=np.int32)
     got, _, gc = run_cross(eng, pop[None], idx, 9, 0)
     assert gebv_close(gc[0], co.gebv(got[0], eff, want64=True)[1], eff)
+
+
+def test_empty_and_degenerate_calls(rng):
+    """zero crosses / zero rows / a single marker / a single cross: nothing faults, keys still advance
+    the way the oracle's do"""
+    M = 40
+    r = np.full(M, 0.1, np.float32)
+    eng = make_engine(r, np.ones((M, 1), np.float32))
+    pool = rng.integers(0, 2, (2, 3, M, 2), dtype=np.uint8)
+    rows = eng.upload_population(pool.reshape(6, M, 2))
+    key = co.key_from_seed(3).copy()
+    out = eng.empty_population(2)
+    empty_idx = torch.empty((2, 0, 2), dtype=torch.int32, device=eng.device)
+    eng.cross(rows, 2, 3, empty_idx, 0, key, 0, out, None)  # n_out = 0
+    _, refkey = co.cross(pool, np.empty((2, 0, 2), np.int32), r, co.key_from_seed(3), 0)
+    assert np.array_equal(key, refkey)
+    eng.cross(rows, 0, 3, empty_idx, 0, key, 1, out, None)  # no envs
+    assert eng.gebv(eng.empty_population(0)).shape == (0, 1)
+    eng.gather(rows, torch.empty((0,), dtype=torch.int32, device=eng.device), out, None)
+    assert eng.topk(torch.randn(3, 10, device=eng.device), 0).shape == (3, 0)
+    with pytest.raises(ValueError):
+        eng.cross(rows, 2, 3, torch.zeros((2, 1, 2), dtype=torch.int32, device=eng.device), 1, key, 0, rows, None)  # aliasing
+    with pytest.raises(ValueError):
+        eng.cross(rows, 2, 3, torch.zeros((2, 1, 2), dtype=torch.int32, device=eng.device), 1, key, 7, out, None)  # bad mode
+    one = make_engine(np.float32([0.5]), np.float32([[2.0]]))  # a single marker
+    p1 = np.array([[[[0, 1]], [[1, 1]]]], np.uint8)
+    got, _, g = run_cross(one, p1, np.array([[[0, 1]]], np.int32), 1, 0)
+    ref, _ = co.cross(p1, np.array([[[0, 1]]], np.int32), np.float32([0.5]), co.key_from_seed(1), 0)
+    assert np.array_equal(got, ref) and g[0, 0, 0] == 2.0 * ref.sum()
+
+
+def test_population_sharded_flow_single_rank(rng):
+    """ShardedPopulation with world_size 1 on the device: global top-k, replicated winners, one
+    generation -- the collectives degenerate to identities, the kernels are the real ones"""
+    from breedgym_amd import Simulator
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector.distributed import ShardedPopulation
+
+    M, N, k = 1000, 300, 30
+    gm = synthetic_genetic_map(M, n_chr=3)
+    geno = synthetic_genotypes(N, M).view(np.uint8)
+    sim = Simulator(genetic_map=gm, seed=0)
+    sp = ShardedPopulation(sim, sim.engine.upload_population(geno))
+    best = sp.global_topk(sp.gebv()[:, 0], k)
+    assert np.array_equal(best.cpu().numpy(), co.topk(co.gebv(geno, gm.marker_effects)[:, 0], k))
+    parents = sp.gather_rows(best)
+    assert np.array_equal(sim.engine.download_population(parents).view(np.uint8), geno[best.cpu().numpy()])
+    pairs = torch.from_numpy(rng.integers(0, k, (N, 2), dtype=np.int32))
+    key = co.key_from_seed(5).copy()
+    g = sp.select_and_cross(k, pairs, key)
+    ref, refkey = co.cross(geno[best.cpu().numpy()][None], pairs.numpy()[None], gm.recombination_vec, co.key_from_seed(5), 1)
+    assert np.array_equal(sim.engine.download_population(sp.rows).view(np.uint8), ref[0]) and np.array_equal(key, refkey)
+    assert gebv_close(np.asarray(g), co.gebv(ref[0], gm.marker_effects, want64=True)[1], gm.marker_effects)
