@@ -1,8 +1,7 @@
-"""Path constants (reference: breedgym/utils/paths.py:6-9)."""
-import pathlib
+"""Where packaged data would live (the reference keeps its sample populations and genetic maps in
+``breedgym/data``; this package ships none -- benchmarks synthesise their inputs, see synthetic.py)."""
+from pathlib import Path
 
-__all__ = ["PROJECT_PATH", "DATA_PATH", "CODE_PATH"]
-
-PROJECT_PATH = pathlib.Path(__file__).parents[2]
-CODE_PATH = pathlib.Path(__file__).parents[1]
-DATA_PATH = CODE_PATH.joinpath("data")
+CODE_PATH = Path(__file__).resolve().parent.parent
+DATA_PATH = CODE_PATH / "data"
+PROJECT_PATH = CODE_PATH.parent
