@@ -80,6 +80,7 @@ struct bh_ctx {
   int32_t *d_cand_i[2] = {nullptr, nullptr};
   int64_t cand_cap = 0;
   bool big_lds_set = false;
+  bool select_lds_set = false;
 };
 
 namespace {
@@ -714,6 +715,25 @@ int bh_topk(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t
     BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::topk_chunk_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
     c->big_lds_set = true;
+  }
+  if (n > kTopkChunk) {
+    // long vectors: radix select of the k-th key, then sort only the k winners in LDS
+    bh::TopkSelectParams q{};
+    q.scores = d_scores;
+    q.out_idx = d_idx_out;
+    q.n = (int32_t)n;
+    q.k = (int32_t)k;
+    q.P = 2;
+    while (q.P < k) q.P <<= 1;
+    const size_t lds = (size_t)q.P * 8;
+    if (lds > 48 * 1024 && !c->select_lds_set) {
+      BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::topk_select_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
+      c->select_lds_set = true;
+    }
+    hipLaunchKernelGGL(bh::topk_select_kernel, dim3((unsigned)n_rows), dim3(1024), lds, c->stream, q);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
   }
   // level 0 reads the caller's scores; every level keeps the best kk of each chunk of <= 16384
   // candidates, until one chunk is left.  top-k of a union = top-k of the parts' top-k.

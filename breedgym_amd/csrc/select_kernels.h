@@ -63,6 +63,89 @@ __device__ __forceinline__ int32_t *shuffle_lds(u32x2 k, int N, int P, int round
   return x;
 }
 
+// ---- top-k of long score vectors: radix select + sort of the winners ---------------------------
+// One workgroup per row.  (1) the k-th largest key T by four 8-bit histogram passes, most
+// significant digit first; (2) everything above T, plus the lowest-index `need` elements equal to
+// T (block scan in index order), is compacted into LDS as (~key << 32 | index); (3) a bitonic sort of
+// those k <= 16384 words gives jax.lax.top_k's order: descending score, ties to the lower index.
+struct TopkSelectParams {
+  const float *scores;  // (rows, n)
+  int32_t *out_idx;     // (rows, k)
+  int32_t n, k, P;      // P = power of two >= k
+};
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(const TopkSelectParams p) {
+  extern __shared__ __align__(16) uint64_t sel[];  // P words
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_need, s_count, s_wave[16], s_running;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
+  const float *sc = p.scores + (int64_t)blockIdx.x * p.n;
+
+  if (tid == 0) {
+    s_prefix = 0;
+    s_need = (unsigned)p.k;
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int j = tid; j < 256; j += nt) hist[j] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int j = tid; j < p.n; j += nt) {
+      const unsigned key = orderable(sc[j]);
+      if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned need = s_need;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (hist[d] >= need) break;
+        need -= hist[d];
+      }
+      s_need = need;
+      s_prefix = (prefix << 8) | (unsigned)d;
+    }
+    __syncthreads();
+  }
+  const unsigned T = s_prefix, need = s_need;  // `need` of the elements equal to T are taken
+  const unsigned n_gt = (unsigned)p.k - need;
+
+  if (tid == 0) {
+    s_count = 0;
+    s_running = 0;
+  }
+  for (int j = tid; j < p.P; j += nt) sel[j] = ~0ull;
+  __syncthreads();
+  // above the threshold: any order (they are sorted afterwards)
+  for (int j = tid; j < p.n; j += nt) {
+    const unsigned key = orderable(sc[j]);
+    if (key > T) sel[atomicAdd(&s_count, 1u)] = ((uint64_t)(~key) << 32) | (uint32_t)j;
+  }
+  // equal to the threshold: the first `need` in index order
+  for (int base = 0; base < p.n; base += nt) {
+    if (s_running >= need) break;  // uniform: read after the barrier that ended the previous trip
+    const int j = base + tid;
+    const bool eq = j < p.n && orderable(sc[j]) == T;
+    const uint64_t bal = __ballot(eq);
+    if (lane == 0) s_wave[wv] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned before = s_running;
+    for (int w = 0; w < wv; ++w) before += s_wave[w];
+    const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (eq && rank < need) sel[n_gt + rank] = ((uint64_t)(~T) << 32) | (uint32_t)j;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned tot = 0;
+      for (int w = 0; w < (nt >> 6); ++w) tot += s_wave[w];
+      s_running += tot;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  bitonic_sort_lds(sel, p.P);
+  for (int j = tid; j < p.k; j += nt) p.out_idx[(int64_t)blockIdx.x * p.k + j] = (int32_t)(uint32_t)sel[j];
+}
+
 struct SelectionParams {
   const float *scores;  // (E, n)
   int32_t *actions;     // (E, n, 2) out
