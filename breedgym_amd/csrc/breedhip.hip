@@ -53,6 +53,7 @@ struct bh_ctx {
   int32_t half = 0, nwh = 0, nw = 0, nvec = 0;
   int64_t effPitch = 0;
   uint32_t *d_thrA = nullptr, *d_thrB = nullptr;  // 32-bit thresholds (thr23 << 9)
+  uint32_t *d_ctrB = nullptr;                     // second Threefry counter per pair
   uint64_t *d_alwA = nullptr, *d_alwB = nullptr;  // site words of markers with r >= 1, or null
   int64_t nthr = 0;
   double *d_eff = nullptr;  // (T, effPitch)
@@ -138,6 +139,7 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
   m.Z = c->d_Z[buf];
   m.thrA = c->d_thrA;
   m.thrB = c->d_thrB;
+  m.ctrB = c->d_ctrB;
   m.alwA = c->d_alwA;
   m.alwB = c->d_alwB;
   m.thr_bytes = (uint32_t)(c->nthr * 4);
@@ -367,7 +369,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   // bits < (t23 << 9); t23 = 2^23 (r >= 1, always) does not fit and becomes an always-set bit.
   const int64_t nthr = (int64_t)(c->nwh + 16) * 64;  // + the trips the kernel prefetches ahead
   c->nthr = nthr;
-  std::vector<uint32_t> thrA(nthr, 0u), thrB(nthr, 0u);
+  std::vector<uint32_t> thrA(nthr, 0u), thrB(nthr, 0u), ctrB(nthr, 0u);
   std::vector<uint64_t> alwA((size_t)c->nwh, 0ull), alwB((size_t)c->nwh, 0ull);
   bool any_always = false;
   for (int64_t j = 0; j < c->half; ++j) {
@@ -379,6 +381,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
       thrA[j] = ta << 9;
     }
     if (j + c->half < n_markers) {
+      ctrB[j] = (uint32_t)(j + c->half);
       const uint32_t tb = bh::threshold23(recomb_vec[j + c->half]);
       if (tb >> 23) {
         alwB[(size_t)(j >> 6)] |= 1ull << (j & 63);
@@ -408,6 +411,8 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   BH_HIP_C(hipMalloc(&c->d_eff, eff.size() * sizeof(double)));
   BH_HIP_C(hipMemcpy(c->d_thrA, thrA.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
   BH_HIP_C(hipMemcpy(c->d_thrB, thrB.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
+  BH_HIP_C(hipMalloc(&c->d_ctrB, nthr * sizeof(uint32_t)));
+  BH_HIP_C(hipMemcpy(c->d_ctrB, ctrB.data(), nthr * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (any_always) {
     BH_HIP_C(hipMalloc(&c->d_alwA, alwA.size() * sizeof(uint64_t)));
     BH_HIP_C(hipMalloc(&c->d_alwB, alwB.size() * sizeof(uint64_t)));
@@ -472,6 +477,7 @@ int bh_destroy(bh_ctx *c) {
     if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
+  if (c->d_ctrB) (void)hipFree(c->d_ctrB);
   if (c->d_alwA) (void)hipFree(c->d_alwA);
   for (auto *b : c->d_Bpack)
     if (b) (void)hipFree(b);

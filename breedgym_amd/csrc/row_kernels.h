@@ -38,6 +38,7 @@ struct MaskParams {
   uint8_t *Z;            // (n_rows, zpitch) interleaved crossover masks, out
   const uint32_t *thrA;  // [(nwh+16)*64] 32-bit thresholds of markers [0, half), zero padded
   const uint32_t *thrB;  // [(nwh+16)*64] 32-bit thresholds of markers [half, M), zero padded
+  const uint32_t *ctrB;  // [(nwh+16)*64] second Threefry counter of pair j: j + half, or 0 where that is >= M
   const uint64_t *alwA;  // [nwh] site words that are always set (r >= 1), or null if there are none
   const uint64_t *alwB;
   int64_t zpitch;        // bytes per cross = 16 * nw
@@ -185,18 +186,14 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   // as whole scalar words; the four ballots of a trip go to LDS with two 16-byte stores.
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void *)p.thrA, 0, p.thr_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)p.thrB, 0, p.thr_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctrB, 0, p.thr_bytes, 0x00020000);
   const uint32_t voff = lane * 4u;
-  const uint32_t c1a = rk01 + (uint32_t)p.half, c1b = rk11 + (uint32_t)p.half;
-  const bool odd = (p.M & 1) != 0;
 
-#define BH_TRIP(T_, J_, TA_, TB_)                                                                                   \
+  /* the second counter comes from a table too (j + half, but 0 for the pad slot of an odd-length    \
+     stream): no compare/select in the loop */                                                                     \
+#define BH_TRIP(T_, J_, TA_, TB_, C1_)                                                                              \
   {                                                                                                                 \
-    uint32_t a0 = (J_) + rk00, a1 = (J_) + c1a, b0 = (J_) + rk10, b1 = (J_) + c1b;                                  \
-    if (odd && (T_) == p.nwh - 1) { /* the pad counter (0) of an odd-length stream */                               \
-      const bool pad = (J_) + (uint32_t)p.half >= (uint32_t)p.M;                                                    \
-      a1 = pad ? rk01 : a1;                                                                                         \
-      b1 = pad ? rk11 : b1;                                                                                         \
-    }                                                                                                               \
+    uint32_t a0 = (J_) + rk00, a1 = (C1_) + rk01, b0 = (J_) + rk10, b1 = (C1_) + rk11;                              \
     asm volatile(BH_TFA BH_TFB                                                                                      \
                  : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                           \
                  : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
@@ -225,15 +222,19 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     constexpr uint32_t STEP = 256u * WAVES;
     uint32_t tA0 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff, 0);
     uint32_t tB0 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff, 0);
+    uint32_t cB0 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff, 0);
     uint32_t tA1 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + STEP, 0);
     uint32_t tB1 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + STEP, 0);
+    uint32_t cB1 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff + STEP, 0);
     while (t < p.nwh) {
-      BH_TRIP(t, j, tA0, tB0)
+      BH_TRIP(t, j, tA0, tB0, cB0)
       tA0 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + 2u * STEP, 0);
       tB0 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + 2u * STEP, 0);
-      if (t + WAVES < p.nwh) BH_TRIP(t + WAVES, j + 64u * WAVES, tA1, tB1)
+      cB0 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff + 2u * STEP, 0);
+      if (t + WAVES < p.nwh) BH_TRIP(t + WAVES, j + 64u * WAVES, tA1, tB1, cB1)
       tA1 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + 3u * STEP, 0);
       tB1 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + 3u * STEP, 0);
+      cB1 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff + 3u * STEP, 0);
       t += 2 * WAVES;
       j += 128u * WAVES;
       soff += 2u * STEP;
