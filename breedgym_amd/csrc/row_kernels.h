@@ -299,11 +299,6 @@ __device__ __forceinline__ uint32_t orderable(float f) {
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-__device__ __forceinline__ float from_orderable(uint32_t u) {
-  u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
-  return __uint_as_float(u);
-}
-
 // offspring dword k of one 16-byte vector: dword k holds markers 2k, 2k+1 as bytes
 // [m0 a0, m0 a1, m1 a0, m1 a1]; output byte (marker, p) = parent p's byte (marker, mask_p).
 // zz = the vector's 16 mask bits (low byte gamete 0, high byte gamete 1).  nibble =

@@ -12,10 +12,8 @@ reference tree; the per-line selection follows the intent shown in ``scripts/tim
 (``vmap(simulator.select)`` over lines).
 """
 import numpy as np
-import torch
 
 from .. import spaces
-from ..engine import DeviceArray
 from .vec_wrappers import PairScores, VectorWrapper
 
 

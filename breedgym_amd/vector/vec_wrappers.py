@@ -10,13 +10,13 @@ directly in front of ``VecBreedGym.step``; the conversion runs on the GPU so tha
   small device ops for the softmax-proportional repeat.
 * ``RavelIndex``      -- flat index -> (row, col).
 """
-from math import ceil, prod
+from math import prod
 from typing import Optional
 
 import numpy as np
 import torch
 
-from .. import rng, spaces
+from .. import spaces
 from ..engine import DeviceArray
 from .vec_env import VecBreedGym
 
