@@ -129,34 +129,47 @@ class ShardedPopulation:
         best = self.eng.topk(flat_s[order], k).to(torch.int64)
         return flat_i[order][best]
 
-    def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
-        """The genotype rows of `global_idx` (k,), replicated on every rank: each rank contributes the
-        rows it owns (padded to k so that one all-gather moves them), the rest is selected locally."""
-        k = global_idx.numel()
+    def replicate_winners(self, global_idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Replicate the genotype rows of `global_idx` (k,) on every rank with one all-gather.
+
+        Returns ``(pool, slot)``: `pool` is (W * c, pitch) -- rank r's block holds the winners it owns,
+        in the order they appear in `global_idx`, padded to c = the largest per-rank count -- and
+        `slot[j]` is the pool row of winner j.  `global_idx` is identical on every rank, so owners,
+        counts and slots are computed locally; only the rows travel."""
+        W = self.world_size
         owner = torch.div(global_idx, self.n_local, rounding_mode="floor")
+        onehot = owner.unsqueeze(1) == torch.arange(W, device=owner.device).unsqueeze(0)  # (k, W)
+        counts = onehot.sum(dim=0)
+        pos = (onehot.cumsum(dim=0) - 1).gather(1, owner.unsqueeze(1)).squeeze(1)  # rank among the owner's winners
+        c = max(int(counts.max()), 1)
         mine = owner == self.rank
-        local_idx = (global_idx - self.rank * self.n_local)[mine].to(torch.int32)
-        send = torch.zeros((k, self.rows.shape[1]), dtype=torch.uint8, device=self.rows.device)
+        local_idx = (global_idx - self.rank * self.n_local)[mine].to(torch.int32).contiguous()
+        send = torch.empty((c, self.rows.shape[1]), dtype=torch.uint8, device=self.rows.device)
         if local_idx.numel():
-            self.eng.gather(self.rows, local_idx.contiguous(), send)
-        allrows = self._all_gather(send)  # (W, k, pitch)
-        counts = self._all_gather(mine.sum().reshape(1)).reshape(-1)  # winners per rank
-        # position of winner j inside its owner's block = its rank among that owner's winners
-        pos = torch.zeros(k, dtype=torch.int64, device=global_idx.device)
-        for r in range(self.world_size):
-            m = owner == r
-            pos[m] = torch.arange(int(counts[r]), device=global_idx.device)
-        return allrows[owner, pos]
+            self.eng.gather(self.rows, local_idx, send[: local_idx.numel()])
+        if local_idx.numel() < c:
+            send[local_idx.numel():].zero_()  # padding rows are never indexed; keep them valid genotypes
+        pool = self._all_gather(send).reshape(W * c, -1)
+        return pool, (owner * c + pos).to(torch.int32)
+
+    def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
+        """The genotype rows of `global_idx` (k,), in that order, replicated on every rank."""
+        pool, slot = self.replicate_winners(global_idx)
+        out = torch.empty((global_idx.numel(), pool.shape[1]), dtype=torch.uint8, device=pool.device)
+        self.eng.gather(pool, slot.contiguous(), out)
+        return out
 
     def select_and_cross(self, k: int, pairs_local: torch.Tensor, key: np.ndarray) -> DeviceArray:
         """One generation: global top-k by GEBV (first trait), replicate the winners, cross this rank's
-        shard of the next generation.  `pairs_local` (n_local, 2) int32 indexes the k winners."""
+        shard of the next generation.  `pairs_local` (n_local, 2) int32 indexes the k winners; the
+        crosses read the all-gathered pool in place through the winners' slots."""
         scores = self.gebv()[:, 0]
         best = self.global_topk(scores, k)
-        parents = self.gather_rows(best)
+        pool, slot = self.replicate_winners(best)
         out = self.eng.empty_population(self.n_local)
         gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
-        idx = pairs_local.reshape(1, -1, 2).to(device=self.eng.device, dtype=torch.int32).contiguous()
-        self.eng.cross(parents.contiguous(), 1, k, idx, self.n_local, key, 1, out, gebv)
+        pairs = pairs_local.reshape(-1).to(device=slot.device, dtype=torch.int64)
+        idx = slot[pairs].reshape(1, -1, 2).contiguous()
+        self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
         self.rows = out
         return DeviceArray.wrap(gebv)
