@@ -4,12 +4,12 @@ Public surface mirrors the reference package (``breedgym/__init__.py:4-34``):
 ``VecBreedGym``, ``BreedGym`` and -- when gymnasium is installed -- the same registered ids.
 """
 from .breedgym import BreedGym
-from .engine import DeviceArray, HipEngine
+from .engine import DeviceArray, HipEngine, PackedPopulation
 from .simulator import Simulator, TraitModel
 from .vector.vec_env import VecBreedGym
 
 __version__ = "0.1.0"
-__all__ = ["BreedGym", "VecBreedGym", "Simulator", "TraitModel", "HipEngine", "DeviceArray"]
+__all__ = ["BreedGym", "VecBreedGym", "Simulator", "TraitModel", "HipEngine", "DeviceArray", "PackedPopulation"]
 
 try:  # same ids as the reference, under this package's entry points
     from gymnasium.envs.registration import register as _register

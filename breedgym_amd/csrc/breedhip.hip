@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "gebv_mfma.h"
+#include "packed_kernels.h"
 #include "row_kernels.h"
 #include "select_kernels.h"
 #include "threefry.h"
@@ -210,6 +211,61 @@ int launch_cross_mw(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp
   }
 }
 
+// ---- packed (bit-plane) rows: packed_kernels.h ------------------------------------------------
+// rows one wave streams at once when there are many (BH_PACKED_R: tuning experiments only)
+#ifndef BH_PACKED_R
+#define BH_PACKED_R 2
+#endif
+constexpr int kRowsPerWavePacked = BH_PACKED_R;
+
+template <int TT, int MW, int R>
+int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
+  rp.n_blocks = (rp.n_rows + 4 * R - 1) / (4 * R);
+  const size_t lds = (size_t)mp.group_lds * (4 / MW);
+  const int grid = rp.n_blocks > mp.n_blocks ? rp.n_blocks : mp.n_blocks;
+  hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+template <int MW, int R>
+int launch_pcross_mw(bh_ctx *c, const bh::PackedParams &rp, const bh::MaskParams &mp, int tt) {
+  switch (tt) {
+    case 0: return launch_pcross_tt<0, MW, R>(c, rp, mp);
+    case 1: return launch_pcross_tt<1, MW, R>(c, rp, mp);
+    case 2: return launch_pcross_tt<2, MW, R>(c, rp, mp);
+    case 4: return launch_pcross_tt<4, MW, R>(c, rp, mp);
+    default: return launch_pcross_tt<8, MW, R>(c, rp, mp);
+  }
+}
+
+template <int TT, int MODE, int R>
+int launch_prow(const bh_ctx *c, bh::PackedParams p) {
+  p.n_blocks = (p.n_rows + 4 * R - 1) / (4 * R);
+  hipLaunchKernelGGL((bh::packed_row_kernel<TT, MODE, R>), dim3((unsigned)p.n_blocks), dim3(256), 0, c->stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_row_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+template <int MODE, int R>
+int launch_prow_r(const bh_ctx *c, const bh::PackedParams &p, int tt) {
+  switch (tt) {
+    case 0: return launch_prow<0, MODE, R>(c, p);
+    case 1: return launch_prow<1, MODE, R>(c, p);
+    case 2: return launch_prow<2, MODE, R>(c, p);
+    case 4: return launch_prow<4, MODE, R>(c, p);
+    default: return launch_prow<8, MODE, R>(c, p);
+  }
+}
+
+template <int MODE>
+int launch_prow_mode(const bh_ctx *c, const bh::PackedParams &p, int tt) {
+  // few rows: one per wave keeps more waves in flight
+  return p.n_rows < 4096 ? launch_prow_r<MODE, 1>(c, p, tt) : launch_prow_r<MODE, kRowsPerWavePacked>(c, p, tt);
+}
+
 // few crosses need masks (they are shared by all envs, or the batch is small): put four waves on
 // each so that the mask role is as short as the streaming beside it
 int mask_waves_for_runahead(const bh_ctx *c, int64_t B) { return (B * 4 <= 2048 || c->M > 16384) ? 4 : 1; }
@@ -236,6 +292,18 @@ bh::RowParams base_params(const bh_ctx *c) {
   p.effPitch = c->effPitch;
   p.zpitch = (int64_t)16 * c->nw;
   p.nvec = c->nvec;
+  p.T = (int32_t)c->T;
+  return p;
+}
+
+bh::PackedParams packed_params(const bh_ctx *c) {
+  bh::PackedParams p{};
+  p.eff = c->d_eff;
+  p.pitch = c->pitch;
+  p.effPitch = c->effPitch;
+  p.zpitch = (int64_t)16 * c->nw;
+  p.nvec = c->nvec;
+  p.nvp = 8 * c->nw;
   p.T = (int32_t)c->T;
   return p;
 }
@@ -303,6 +371,22 @@ int gebv_chunks(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, in
     p.eff = c->d_eff + (int64_t)t0 * c->effPitch;
     int rc = launch_row_mode<bh::MODE_GEBV>(c, p, tt_for(p.tcount));
     if (rc) return rc;
+  }
+  return BH_OK;
+}
+
+// GEBV of packed rows, trait chunks [t_begin, T), fused f64 path (packed_kernels.h)
+int packed_gebv_chunks(bh_ctx *c, const uint16_t *d_rows, int64_t rows, float *d_gebv, int t_begin) {
+  for (int t0 = t_begin; t0 < c->T; t0 += kMaxFusedTraits) {
+    bh::PackedParams p = packed_params(c);
+    p.src = d_rows;
+    p.gebv = d_gebv;
+    p.n_pool = (int32_t)rows;
+    p.n_rows = (int32_t)rows;
+    p.t0 = t0;
+    p.tcount = (int32_t)std::min<int64_t>(kMaxFusedTraits, c->T - t0);
+    p.eff = c->d_eff + (int64_t)t0 * c->effPitch;
+    if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;
   }
   return BH_OK;
 }
@@ -567,28 +651,34 @@ int bh_download_population(bh_ctx *c, const uint8_t *d_src, int64_t rows, uint8_
   return BH_OK;
 }
 
-int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
-             int64_t n_out, uint32_t sim_key[2], int rng_mode, uint8_t *d_out, float *d_gebv, float *d_reward) {
+// bh_cross and bh_cross_packed: `packed` selects the layout of the pool and of d_out_packed;
+// d_out_bytes is the byte-layout offspring (required unless packed, optional when packed).
+static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_pool, int64_t n_envs,
+                      int64_t pool_rows, const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
+                      uint8_t *d_out_bytes, uint16_t *d_out_packed, float *d_gebv, float *d_reward) {
   if (int rc = check_ctx(c)) return rc;
-  if (!sim_key) return fail(BH_ERR_BAD_ARG, "bh_cross: null sim_key");
-  if (n_envs < 0 || n_out < 0 || pool_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_cross: negative size");
+  if (!sim_key) return fail(BH_ERR_BAD_ARG, "%s: null sim_key", who);
+  if (n_envs < 0 || n_out < 0 || pool_rows < 0) return fail(BH_ERR_BAD_ARG, "%s: negative size", who);
   if (rng_mode < 0 || rng_mode > (BH_RNG_INDEPENDENT | BH_RNG_DOUBLE_HAPLOID))
-    return fail(BH_ERR_BAD_ARG, "bh_cross: unknown rng_mode %d", rng_mode);
+    return fail(BH_ERR_BAD_ARG, "%s: unknown rng_mode %d", who, rng_mode);
   const bool dh = (rng_mode & BH_RNG_DOUBLE_HAPLOID) != 0;
   const bool shared = (rng_mode & BH_RNG_INDEPENDENT) == 0;
   const int64_t rows = n_envs * n_out;
   const int64_t B = shared ? n_out : rows;
   const int64_t nkeys = dh ? B + 1 : 2 * B + 1;
   if (rows > 0x3FFFFFFF || n_envs * pool_rows > 0x7FFFFFFF || 2 * nkeys > 0xFFFFFFFFll)
-    return fail(BH_ERR_UNSUPPORTED, "bh_cross: too many rows for 32-bit indexing");
+    return fail(BH_ERR_UNSUPPORTED, "%s: too many rows for 32-bit indexing", who);
   if (rows > 0) {
-    if (!d_pool || !d_idx || !d_out) return fail(BH_ERR_BAD_ARG, "bh_cross: null device pointer");
-    if (pool_rows == 0) return fail(BH_ERR_BAD_ARG, "bh_cross: empty parent pool");
-    if (d_gebv && c->T == 0) return fail(BH_ERR_BAD_ARG, "bh_cross: GEBV requested but the context has no traits");
-    if (d_reward && !d_gebv) return fail(BH_ERR_BAD_ARG, "bh_cross: the reward needs the GEBV output");
-    const uint8_t *pool_end = d_pool + n_envs * pool_rows * c->pitch;
-    const uint8_t *out_end = d_out + rows * c->pitch;
-    if (d_out < pool_end && d_pool < out_end) return fail(BH_ERR_BAD_ARG, "bh_cross: d_out aliases d_pool");
+    if (!d_pool || !d_idx || (packed ? !d_out_packed : !d_out_bytes))
+      return fail(BH_ERR_BAD_ARG, "%s: null device pointer", who);
+    if (pool_rows == 0) return fail(BH_ERR_BAD_ARG, "%s: empty parent pool", who);
+    if (d_gebv && c->T == 0) return fail(BH_ERR_BAD_ARG, "%s: GEBV requested but the context has no traits", who);
+    if (d_reward && !d_gebv) return fail(BH_ERR_BAD_ARG, "%s: the reward needs the GEBV output", who);
+    const int64_t row_bytes = packed ? (int64_t)16 * c->nw : c->pitch;
+    const uint8_t *pool_lo = static_cast<const uint8_t *>(d_pool), *pool_end = pool_lo + n_envs * pool_rows * row_bytes;
+    const uint8_t *out_lo = packed ? reinterpret_cast<const uint8_t *>(d_out_packed) : d_out_bytes;
+    const uint8_t *out_end = out_lo + rows * row_bytes;
+    if (out_lo < pool_end && pool_lo < out_end) return fail(BH_ERR_BAD_ARG, "%s: the output aliases the pool", who);
 
     // ---- this generation's masks: made by the previous call's launch, or made now
     const int64_t zbytes = B * 16 * c->nw;
@@ -609,53 +699,166 @@ int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows
 
   if (rows > 0) {
     const int buf = c->last_buf;
-    bh::RowParams p = base_params(c);
-    p.src = d_pool;
-    p.out = d_out;
-    p.idx = d_idx;
-    p.gebv = d_gebv;
-    p.Z = c->d_Z[buf];
-    p.n_pool = (int32_t)pool_rows;
-    p.n_out = (int32_t)n_out;
-    p.n_rows = (int32_t)rows;
-    p.rng_shared = shared;
-    const bool fused = d_gebv && c->T <= kMaxFusedTraits && !use_mfma_gebv(c, rows);
-    p.t0 = 0;
-    p.tcount = fused ? (int32_t)c->T : 0;
-    if (c->prefetch && row_waves_for(c, rows) == 1) {
-      // run ahead: the next generation's masks need only the advanced key and the batch size, so
-      // the same launch makes them (mask role) while it streams this generation (row role)
+    // GEBV inside the streaming launch (f64 VALU) for few traits; from 3 traits on the int8-MFMA
+    // pass over the byte-layout offspring is faster -- when there are byte-layout offspring
+    const bool mfma_after = d_gebv && d_out_bytes && use_mfma_gebv(c, rows);
+    const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
+    const int tcount = fused ? (int32_t)c->T : 0;
+    // run ahead: the next generation's masks need only the advanced key and the batch size, so
+    // the same launch makes them (mask role) while it streams this generation (row role)
+    const bool run_ahead = c->prefetch && (packed || row_waves_for(c, rows) == 1);
+    bh::MaskParams mp{};
+    int mw = 1;
+    if (run_ahead) {
       if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
+      mw = mask_waves_for_runahead(c, B);
+      mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh);
+    }
+    const bool wide = rows >= 4096;  // else one row per wave: more waves in flight
+    int rc;
+    if (packed) {
+      bh::PackedParams p = packed_params(c);
+      p.src = static_cast<const uint16_t *>(d_pool);
+      p.outp = d_out_packed;
+      p.outb = d_out_bytes;
+      p.idx = d_idx;
+      p.gebv = d_gebv;
       p.Z = c->d_Z[buf];
-      const int mw = mask_waves_for_runahead(c, B);
-      const bh::MaskParams mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh);
-      const bool wide = p.n_rows >= 4096;  // else one row per wave: more waves in flight
-      int rc;
-      if (mw == 1)
-        rc = wide ? launch_cross_mw<1, kRowsPerWaveCross>(c, p, mp, tt_for(p.tcount))
-                  : launch_cross_mw<1, 1>(c, p, mp, tt_for(p.tcount));
-      else
-        rc = wide ? launch_cross_mw<4, kRowsPerWaveCross>(c, p, mp, tt_for(p.tcount))
-                  : launch_cross_mw<4, 1>(c, p, mp, tt_for(p.tcount));
-      if (rc) return rc;
+      p.n_pool = (int32_t)pool_rows;
+      p.n_out = (int32_t)n_out;
+      p.n_rows = (int32_t)rows;
+      p.rng_shared = shared;
+      p.tcount = tcount;
+      if (run_ahead) {
+        if (mw == 1)
+          rc = wide ? launch_pcross_mw<1, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
+                    : launch_pcross_mw<1, 1>(c, p, mp, tt_for(tcount));
+        else
+          rc = wide ? launch_pcross_mw<4, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
+                    : launch_pcross_mw<4, 1>(c, p, mp, tt_for(tcount));
+      } else {
+        rc = launch_prow_mode<bh::MODE_CROSS>(c, p, tt_for(tcount));
+      }
+    } else {
+      bh::RowParams p = base_params(c);
+      p.src = static_cast<const uint8_t *>(d_pool);
+      p.out = d_out_bytes;
+      p.idx = d_idx;
+      p.gebv = d_gebv;
+      p.Z = c->d_Z[buf];
+      p.n_pool = (int32_t)pool_rows;
+      p.n_out = (int32_t)n_out;
+      p.n_rows = (int32_t)rows;
+      p.rng_shared = shared;
+      p.t0 = 0;
+      p.tcount = tcount;
+      if (run_ahead) {
+        if (mw == 1)
+          rc = wide ? launch_cross_mw<1, kRowsPerWaveCross>(c, p, mp, tt_for(tcount))
+                    : launch_cross_mw<1, 1>(c, p, mp, tt_for(tcount));
+        else
+          rc = wide ? launch_cross_mw<4, kRowsPerWaveCross>(c, p, mp, tt_for(tcount))
+                    : launch_cross_mw<4, 1>(c, p, mp, tt_for(tcount));
+      } else {
+        rc = launch_row_mode<bh::MODE_CROSS>(c, p, tt_for(tcount));
+      }
+    }
+    if (rc) return rc;
+    if (run_ahead) {
       c->pf.valid = true;
       c->pf.buf = 1 - buf;
       c->pf.key0 = nk.x;
       c->pf.key1 = nk.y;
       c->pf.B = B;
       c->pf.dh = dh;
-    } else {
-      if (int rc = launch_row_mode<bh::MODE_CROSS>(c, p, tt_for(p.tcount))) return rc;
     }
-    if (d_gebv && !fused)
-      if (int rc = gebv_chunks(c, d_out, rows, d_gebv, 0)) return rc;
+    if (d_gebv && !fused) {
+      if (d_out_bytes)
+        rc = gebv_chunks(c, d_out_bytes, rows, d_gebv, 0);
+      else
+        rc = packed_gebv_chunks(c, d_out_packed, rows, d_gebv, 0);
+      if (rc) return rc;
+    }
     // the reward of vec_env.py:97: a 2 us reduction kernel behind the cross launch (an in-launch
     // arrival protocol with atomics was measured slower: +6.6 us against +2.2 us)
     if (d_reward)
-      if (int rc = bh_reward_max(c, d_gebv, n_envs, n_out * c->T, d_reward)) return rc;
+      if (int rc2 = bh_reward_max(c, d_gebv, n_envs, n_out * c->T, d_reward)) return rc2;
   }
   sim_key[0] = nk.x;
   sim_key[1] = nk.y;
+  return BH_OK;
+}
+
+int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
+             int64_t n_out, uint32_t sim_key[2], int rng_mode, uint8_t *d_out, float *d_gebv, float *d_reward) {
+  return cross_impl(c, "bh_cross", false, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode, d_out, nullptr,
+                    d_gebv, d_reward);
+}
+
+int bh_cross_packed(bh_ctx *c, const uint16_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
+                    int64_t n_out, uint32_t sim_key[2], int rng_mode, uint16_t *d_out_packed, uint8_t *d_out_bytes,
+                    float *d_gebv, float *d_reward) {
+  return cross_impl(c, "bh_cross_packed", true, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode,
+                    d_out_bytes, d_out_packed, d_gebv, d_reward);
+}
+
+int64_t bh_packed_pitch(const bh_ctx *c) { return c ? (int64_t)16 * c->nw : 0; }
+
+int bh_pack(bh_ctx *c, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_pack: negative size");
+  if (n_rows == 0) return BH_OK;
+  if (!d_rows || !d_packed) return fail(BH_ERR_BAD_ARG, "bh_pack: null device pointer");
+  if (n_rows > 0x3FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_pack: too many rows");
+  bh::PackParams p{};
+  p.src = d_rows;
+  p.dst = d_packed;
+  p.pitch = c->pitch;
+  p.nvec = c->nvec;
+  p.nvp = 8 * c->nw;
+  p.n_rows = (int32_t)n_rows;
+  hipLaunchKernelGGL(bh::pack_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, c->stream, p);
+  BH_HIP(hipGetLastError());
+  return BH_OK;
+}
+
+int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
+                     uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0 || src_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: negative size");
+  if (n_rows == 0) return BH_OK;
+  if (!d_src) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: null device pointer");
+  if (src_rows == 0) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: empty source");
+  if (!d_idx && n_rows > src_rows) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: more rows than the source holds");
+  if (n_rows > 0x3FFFFFFF || src_rows > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_gather_packed: too many rows");
+  if (d_gebv && c->T == 0)
+    return fail(BH_ERR_BAD_ARG, "bh_gather_packed: GEBV requested but the context has no traits");
+  bh::PackedParams p = packed_params(c);
+  p.src = d_src;
+  p.outp = d_out_packed;
+  p.outb = d_out_bytes;
+  p.idx = d_idx;
+  p.gebv = d_gebv;
+  p.n_pool = (int32_t)src_rows;
+  p.n_rows = (int32_t)n_rows;
+  const bool mfma_after = d_gebv && d_out_bytes && use_mfma_gebv(c, n_rows);
+  const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
+  p.tcount = fused ? (int32_t)c->T : 0;
+  if (p.tcount > 0 || d_out_packed || d_out_bytes)
+    if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;
+  if (d_gebv && !fused) {
+    if (d_out_bytes) return gebv_chunks(c, d_out_bytes, n_rows, d_gebv, 0);
+    // no byte rows to run the matrix-core pass on: f64 passes over the packed rows, through the index
+    for (int t0 = 0; t0 < c->T; t0 += kMaxFusedTraits) {
+      bh::PackedParams q = p;
+      q.outp = nullptr;
+      q.outb = nullptr;
+      q.t0 = t0;
+      q.tcount = (int32_t)std::min<int64_t>(kMaxFusedTraits, c->T - t0);
+      q.eff = c->d_eff + (int64_t)t0 * c->effPitch;
+      if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, q, tt_for(q.tcount))) return rc;
+    }
+  }
   return BH_OK;
 }
 

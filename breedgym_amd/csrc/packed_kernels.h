@@ -1,0 +1,299 @@
+// Bit-plane genotype rows: 1 bit per allele, 8x less to read than the byte layout of the API.
+//
+// A packed row is uint16 P[8 * nw] (nw = ceil(M / 64)): P[v] describes markers 8v .. 8v+7, low byte =
+// their allele-0 bits, high byte = their allele-1 bits (bit t = marker 8v + t); bits of markers
+// >= M are zero.  That is the shape of the crossover-mask rows mask_kernel writes (low byte =
+// gamete 0, high byte = gamete 1), and P[v] is exactly what one lane needs to produce the 16-byte
+// vector v of the byte layout -- so the row role of a cross becomes
+//     three 2-byte loads (parent 0, parent 1, mask)  ->  8+8 bit selects  ->  2-byte store
+//     [-> 16-byte coalesced store of the byte-layout offspring, if the caller wants observations]
+//     [-> f64 GEBV from the expanded vector, as in row_kernels.h]
+// Per cross that is M/2 + M/4 bytes read and M/4 (+ 2M) written instead of 4M read and 2M written;
+// with byte observations on, the launch is bound by the 2M-byte store alone.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "row_kernels.h"
+
+namespace bh {
+
+struct PackedParams {
+  const uint16_t *src;  // cross: (E, n_pool, nvp) packed pool; gather: (n_pool, nvp)
+  uint16_t *outp;       // (rows, nvp) packed rows out, or null
+  uint8_t *outb;        // (rows, pitch) byte-layout rows out, or null
+  const int32_t *idx;   // cross: (rows, 2); gather: (rows) or null (= identity)
+  float *gebv;          // (rows, T) or null
+  const uint8_t *Z;     // cross: (B, zpitch) masks from the mask role
+  const double *eff;    // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
+  int64_t pitch;        // bytes per byte-layout row
+  int64_t effPitch;
+  int64_t zpitch;       // bytes per mask row = bytes per packed row = 16 * nw
+  int32_t nvec;         // 16-byte vectors per byte-layout row = ceil(M / 8)
+  int32_t nvp;          // uint16 words per packed row = 8 * nw >= nvec
+  int32_t n_pool, n_out;
+  int32_t n_rows;
+  int32_t n_blocks;
+  int32_t T, t0, tcount;
+  int32_t rng_shared;
+};
+
+// dword k of byte-layout vector v from its packed word: bytes [a0(2k), a1(2k), a0(2k+1), a1(2k+1)].
+// nib = [a0(2k) a0(2k+1) a1(2k) a1(2k+1)]; the multiply drops its bits onto bit 0 of bytes 0, 2, 1, 3.
+__device__ __forceinline__ uint32_t expand_dword(uint32_t o16, int k) {
+  const uint32_t nib = ((o16 >> (2 * k)) & 3u) | (((o16 >> (8 + 2 * k)) & 3u) << 2);
+  return (nib * 0x00208041u) & 0x01010101u;
+}
+
+__device__ __forceinline__ uint4 expand_vector(uint32_t o16) {
+  return make_uint4(expand_dword(o16, 0), expand_dword(o16, 1), expand_dword(o16, 2), expand_dword(o16, 3));
+}
+
+// the gamete a parent passes on, for 8 markers at once: allele-0 bit where the mask bit is 0,
+// allele-1 bit where it is 1
+__device__ __forceinline__ uint32_t gamete8(uint32_t p16, uint32_t z8) {
+  const uint32_t lo = p16 & 0xffu, hi = p16 >> 8;
+  return lo ^ ((lo ^ hi) & z8);
+}
+
+// One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
+// them, as in row_role); MODE_CROSS or MODE_GATHER.
+//
+// A row is only ceil(M / 512) trips of 64 lanes, and a trip that waits for its own loads costs a full
+// memory latency (measured: 18 us for 4096 x 10k-marker rows whatever the traffic).  So the loads run
+// ahead of the arithmetic: the 2-byte words of the next CH trips and the marker effects of the next
+// trip are requested before the current trip is expanded, stored and summed.  (The compiler cannot
+// do this itself: the byte stores may alias anything.)
+template <int TT, int MODE, int R>
+__device__ __forceinline__ void packed_row_role(const PackedParams &p, const int block, const int wave) {
+  static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
+  constexpr int NT = TT > 0 ? TT : 1;
+  constexpr int CH = R == 1 ? 4 : 2;           // trips whose genotype words are in flight together
+  constexpr bool EPF = TT == 1 || TT == 2;     // effects one trip ahead (16 VGPRs per trait)
+  constexpr int NE = EPF ? TT : 1;
+  constexpr int NC = TT * R <= 4 ? 4 : (TT * R <= 8 ? 2 : 1);  // accumulation chains per (row, trait)
+  const int lane = threadIdx.x & 63;
+  const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
+  if (c0 >= p.n_rows) return;
+
+  const uint16_t *src0[R], *src1[R], *Z16[R];
+  uint16_t *dstp[R];
+  uint8_t *dstb[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    live[r] = c0 + r < p.n_rows;
+    const int c = live[r] ? c0 + r : c0;  // a dead slot re-reads row c0 and writes nothing
+    src1[r] = nullptr;
+    Z16[r] = nullptr;
+    if constexpr (MODE == MODE_CROSS) {
+      const int e = c / p.n_out, i = c - e * p.n_out;
+      const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
+      const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
+      src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
+      src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
+      Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
+    } else {
+      src0[r] = p.src + (int64_t)(p.idx ? norm_index(p.idx[c], p.n_pool) : c) * p.nvp;
+    }
+    dstp[r] = (p.outp && live[r]) ? p.outp + (int64_t)c * p.nvp : nullptr;
+    dstb[r] = (p.outb && live[r]) ? p.outb + (int64_t)c * p.pitch : nullptr;
+  }
+  __builtin_amdgcn_s_setprio(3);
+
+  double acc[R][NT][NC];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) acc[r][t][k] = 0.0;
+
+  const int ntrips = (p.nvp + 63) >> 6;
+  struct Words {
+    uint32_t a[R][CH], b[R][CH], z[R][CH];
+  };
+  // words of trips t0 .. t0+CH-1 for this lane; lanes past the end of the row re-read a word that exists
+  auto load_words = [&](int t0, Words &w) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      int v = (t0 + j) * 64 + lane;
+      v = v < p.nvp ? v : lane & 7;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        w.a[r][j] = src0[r][v];
+        if constexpr (MODE == MODE_CROSS) {
+          w.b[r][j] = src1[r][v];
+          w.z[r][j] = Z16[r][v];
+        } else {
+          w.b[r][j] = 0;
+          w.z[r][j] = 0;
+        }
+      }
+    }
+  };
+  struct Eff8 {
+    double2 e[4];
+  };
+  auto load_eff = [&](int t, int trait) {
+    int v = t * 64 + lane;
+    v = v < p.nvec ? v : p.nvec - 1;
+    const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)trait * p.effPitch + 8 * (int64_t)v);
+    Eff8 r;
+    r.e[0] = ep[0];
+    r.e[1] = ep[1];
+    r.e[2] = ep[2];
+    r.e[3] = ep[3];
+    return r;
+  };
+  // NC independent chains per sum: a single chain of dependent f64 FMAs waits out the FMA latency
+  // eight times per trip when few waves share the SIMD
+  auto accumulate = [&](const Dosage8 &d, const Eff8 &f, double (&s)[NC]) {
+    const double e[8] = {f.e[0].x, f.e[0].y, f.e[1].x, f.e[1].y, f.e[2].x, f.e[2].y, f.e[3].x, f.e[3].y};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k % NC] = fma(d.d[k], e[k], s[k % NC]);
+  };
+
+  Words cur;
+  load_words(0, cur);
+  Eff8 enext[NE];
+  if constexpr (EPF) {
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+      if (t < p.tcount) enext[t] = load_eff(0, t);
+  }
+
+  for (int t0 = 0; t0 < ntrips; t0 += CH) {
+    Words nxt;
+    if (t0 + CH < ntrips) load_words(t0 + CH, nxt);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int t = t0 + j;
+      if (t < ntrips) {
+        const int v = t * 64 + lane;
+        const bool inp = v < p.nvp, inrow = v < p.nvec;
+        Eff8 ecur[NE];
+        if constexpr (EPF) {
+#pragma unroll
+          for (int q = 0; q < TT; ++q)
+            if (q < p.tcount) {
+              ecur[q] = enext[q];
+              if (t + 1 < ntrips) enext[q] = load_eff(t + 1, q);
+            }
+        }
+        uint4 oo[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          uint32_t o = cur.a[r][j];
+          if constexpr (MODE == MODE_CROSS)
+            o = gamete8(cur.a[r][j], cur.z[r][j] & 0xffu) | (gamete8(cur.b[r][j], cur.z[r][j] >> 8) << 8);
+          if (dstp[r] && inp) dstp[r][v] = (uint16_t)o;
+          oo[r] = expand_vector(o);
+          if (dstb[r] && inrow) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)v) = oo[r];
+        }
+        if constexpr (TT > 0) {
+          if (inrow) {
+#pragma unroll
+            for (int q = 0; q < TT; ++q)
+              if (q < p.tcount) {
+                Eff8 f;
+                if constexpr (EPF)
+                  f = ecur[q];
+                else
+                  f = load_eff(t, q);
+#pragma unroll
+                for (int r = 0; r < R; ++r) accumulate(dosages(oo[r]), f, acc[r][q]);
+              }
+          }
+        }
+      }
+    }
+    cur = nxt;
+  }
+
+  if constexpr (TT > 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        double s = acc[r][t][0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k) s += acc[r][t][k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        acc[r][t][0] = s;
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (live[r]) {
+#pragma unroll
+          for (int t = 0; t < TT; ++t)
+            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t][0];
+        }
+    }
+  }
+}
+
+template <int TT, int MODE, int R>
+__global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
+  packed_row_role<TT, MODE, R>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6));
+}
+
+// cross_kernel (row_kernels.h) with the packed row role: waves 0-3 stream generation g, waves 4-7
+// make the masks of generation g+1.
+template <int TT, int MW, int R>
+__global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  __shared__ unsigned counter;
+  const int wave = (int)(threadIdx.x >> 6);
+  if constexpr (MW == 4) {
+    if (threadIdx.x == 0) counter = 0;
+    __syncthreads();
+  }
+#if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation_packed.sh)
+  if (wave < 4) return;
+#elif defined(BH_ABLATE_NO_MASKROLE)
+  if (wave >= 4) return;
+#endif
+  if (wave < 4) {
+    if ((int)blockIdx.x < rp.n_blocks) packed_row_role<TT, MODE_CROSS, R>(rp, (int)blockIdx.x, wave);
+  } else if ((int)blockIdx.x < mp.n_blocks) {
+    if constexpr (MW == 1)
+      mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
+    else
+      mask_role<4, SYNC_COUNTER>(mp, (int)blockIdx.x, wave - 4, lds_raw, &counter);
+  }
+}
+
+// byte-layout rows -> packed rows.  One lane per 16-byte vector.
+struct PackParams {
+  const uint8_t *src;  // (rows, pitch)
+  uint16_t *dst;       // (rows, nvp)
+  int64_t pitch;
+  int32_t nvec, nvp, n_rows;
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= p.n_rows) return;
+  const uint8_t *s = p.src + (int64_t)row * p.pitch;
+  uint16_t *d = p.dst + (int64_t)row * p.nvp;
+  for (int v = lane; v < p.nvp; v += 64) {
+    uint32_t o = 0;
+    if (v < p.nvec) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(s + 16 * (int64_t)v);
+      const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // bit 0 of bytes 0..3 -> bits 0..3: [a0(2k), a1(2k), a0(2k+1), a1(2k+1)]
+        const uint32_t nib = ((dw[k] & 0x01010101u) * 0x01020408u) >> 24;
+        o |= ((nib & 1u) | ((nib >> 1) & 2u)) << (2 * k);
+        o |= (((nib >> 1) & 1u) | ((nib >> 2) & 2u)) << (8 + 2 * k);
+      }
+    }
+    d[v] = (uint16_t)o;
+  }
+}
+
+}  // namespace bh

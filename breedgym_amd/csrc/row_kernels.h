@@ -377,11 +377,16 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
   // behind Threefry, or the memory pipes drain.
   __builtin_amdgcn_s_setprio(3);
 
-  double acc[R][NT];
+  // NC independent chains per sum: one chain of dependent f64 FMAs waits out the FMA latency eight
+  // times per vector when few waves share the SIMD
+  constexpr int NC = NT * R <= 4 ? 4 : (NT * R <= 8 ? 2 : 1);
+  double acc[R][NT][NC];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[r][t] = 0.0;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) acc[r][t][k] = 0.0;
 
   // VPT 16-byte vectors per lane and trip for each of the R rows; all genotype loads of a trip
   // are issued before the first use
@@ -436,16 +441,9 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
 #pragma unroll
               for (int r = 0; r < R; ++r) {
                 const Dosage8 d = dosages(oo[r][u]);
-                double s = acc[r][t];
-                s = fma(d.d[0], e0.x, s);
-                s = fma(d.d[1], e0.y, s);
-                s = fma(d.d[2], e1.x, s);
-                s = fma(d.d[3], e1.y, s);
-                s = fma(d.d[4], e2.x, s);
-                s = fma(d.d[5], e2.y, s);
-                s = fma(d.d[6], e3.x, s);
-                s = fma(d.d[7], e3.y, s);
-                acc[r][t] = s;
+                const double e[8] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, e3.x, e3.y};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[r][t][k % NC] = fma(d.d[k], e[k], acc[r][t][k % NC]);
               }
             }
           }
@@ -459,20 +457,22 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        double s = acc[r][t];
+        double s = acc[r][t][0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k) s += acc[r][t][k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        acc[r][t] = s;
+        acc[r][t][0] = s;
       }
     if constexpr (WAVES > 1) {
       if (lane == 0)
-        for (int t = 0; t < TT; ++t) red[wv * TT + t] = acc[0][t];
+        for (int t = 0; t < TT; ++t) red[wv * TT + t] = acc[0][t][0];
       __syncthreads();
       if (tid == 0)
         for (int t = 0; t < TT; ++t) {
           double s = 0.0;
           for (int w = 0; w < WAVES; ++w) s += red[w * TT + t];
-          acc[0][t] = s;
+          acc[0][t][0] = s;
         }
     }
     if (tid == 0) {
@@ -481,7 +481,7 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
         if (live[r]) {
 #pragma unroll
           for (int t = 0; t < TT; ++t)
-            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
+            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t][0];
         }
     }
   }

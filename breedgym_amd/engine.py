@@ -60,6 +60,36 @@ for _name in ("max", "min", "sum", "mean", "std", "var", "argmax", "argmin", "an
     setattr(DeviceArray, _name, _numpy_style(_name))
 
 
+class PackedPopulation:
+    """A population kept as bit-plane rows: what ``VecBreedGym(storage="bits", observations="lazy")``
+    hands out in place of the byte observation.  It has the observation's ``shape``; ``unpack()``
+    (or ``np.asarray``) expands it to the usual ``(*lead, M, 2)`` bool genotypes on demand."""
+
+    dtype = np.dtype(np.bool_)
+
+    def __init__(self, engine, packed_rows: torch.Tensor, lead):
+        self.engine, self.packed_rows, self.lead = engine, packed_rows, tuple(lead)
+        self._bytes = None
+
+    @property
+    def shape(self):
+        return (*self.lead, self.engine.n_markers, 2)
+
+    def __len__(self):
+        return self.lead[0]
+
+    def unpack(self) -> DeviceArray:
+        if self._bytes is None:
+            self._bytes = self.engine.as_genotypes(self.engine.unpack(self.packed_rows), *self.lead)
+        return self._bytes
+
+    def __array__(self, dtype=None, copy=None):
+        return self.unpack().__array__(dtype)
+
+    def __getitem__(self, item):
+        return self.unpack()[item]
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -75,6 +105,10 @@ class EngineBase:
 
     def empty(self, shape, dtype) -> torch.Tensor:
         return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def empty_packed(self, rows: int) -> torch.Tensor:
+        """Bit-plane rows: ``packed_pitch = 16 * ceil(M / 64)`` bytes each (include/breedhip.h)."""
+        return torch.empty((int(rows), self.packed_pitch), dtype=torch.uint8, device=self.device)
 
     def as_genotypes(self, rows_t: torch.Tensor, *lead) -> DeviceArray:
         """(rows, pitch) uint8 -> zero-copy (*lead, M, 2) bool view."""
@@ -156,6 +190,7 @@ class HipEngine(EngineBase):
         self._h = h
         self._L = L
         self.pitch = int(L.bh_row_pitch(h))
+        self.packed_pitch = int(L.bh_packed_pitch(h))
         # torch's default stream is the null stream, which is also the context's default
 
     def close(self):
@@ -200,6 +235,49 @@ class HipEngine(EngineBase):
         assert idx.dtype == torch.int32 and idx.is_contiguous() and out.shape[0] >= idx.numel()
         _lib.check(
             self._L.bh_gather(self._h, src.data_ptr(), src.shape[0], idx.data_ptr(), idx.numel(), out.data_ptr(), _ptr(gebv))
+        )
+
+    # ---- bit-plane rows (1 bit per allele; include/breedhip.h, "bit-plane storage") -------------
+    def pack(self, rows_t, out=None) -> torch.Tensor:
+        """(rows, pitch) byte-layout rows -> (rows, packed_pitch) packed rows."""
+        if out is None:
+            out = self.empty_packed(rows_t.shape[0])
+        _lib.check(self._L.bh_pack(self._h, rows_t.data_ptr(), rows_t.shape[0], out.data_ptr()))
+        return out
+
+    def unpack(self, packed, out=None) -> torch.Tensor:
+        """(rows, packed_pitch) packed rows -> (rows, pitch) byte-layout rows."""
+        if out is None:
+            out = self.empty_population(packed.shape[0])
+        self.gather_packed(packed, None, packed.shape[0], None, out)
+        return out
+
+    def cross_packed(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes=None,
+                     gebv=None, reward=None) -> None:
+        """``cross`` on a packed pool (bh_cross_packed); ``out_bytes`` also receives the byte-layout offspring."""
+        assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_envs * n_out * 2
+        assert pool.shape[0] >= n_envs * pool_rows and out_packed.shape[0] >= n_envs * n_out
+        assert out_bytes is None or out_bytes.shape[0] >= n_envs * n_out
+        assert gebv is None or (gebv.dtype == torch.float32 and gebv.numel() >= n_envs * n_out * self.n_traits)
+        _lib.check(
+            self._L.bh_cross_packed(
+                self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
+                key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out_packed.data_ptr(),
+                _ptr(out_bytes), _ptr(gebv), _ptr(reward),
+            )
+        )
+
+    def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None) -> None:
+        """Rows ``idx`` (or 0..n_rows-1) of packed ``src`` -> packed and/or byte-layout rows and/or GEBV."""
+        assert idx is None or (idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_rows)
+        assert out_packed is None or out_packed.shape[0] >= n_rows
+        assert out_bytes is None or out_bytes.shape[0] >= n_rows
+        _lib.check(
+            self._L.bh_gather_packed(
+                self._h, src.data_ptr(), src.shape[0], _ptr(idx), int(n_rows), _ptr(out_packed), _ptr(out_bytes),
+                _ptr(gebv),
+            )
         )
 
     def gebv(self, pop, out=None) -> torch.Tensor:

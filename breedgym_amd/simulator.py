@@ -140,6 +140,14 @@ class Simulator:
         self.engine.cross(pool_rows_t, n_envs, pool_rows, idx, n_out, key, rng_mode, out_rows_t, gebv, reward)
         self.random_key = key
 
+    def cross_indexed_packed(self, pool_packed, n_envs, pool_rows, idx, n_out, out_packed, out_bytes=None, gebv=None,
+                             rng_mode: int = _lib.RNG_SHARED_ENVS, reward=None) -> None:
+        """``cross_indexed`` on bit-plane rows; ``out_bytes`` also receives the byte-layout offspring."""
+        key = np.ascontiguousarray(self.random_key, np.uint32)
+        self.engine.cross_packed(pool_packed, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes,
+                                 gebv, reward)
+        self.random_key = key
+
     def cross(self, parents) -> DeviceArray:
         """``Simulator.cross(parents)``: parents (n, 2, M, 2) -> offspring (n, M, 2)."""
         shape = tuple(parents.shape)

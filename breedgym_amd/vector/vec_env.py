@@ -14,7 +14,12 @@ Differences a caller can see, all opt-in or benign:
   * ``env_rng="independent"`` gives every env its own crossover randomness; the default
     ``"shared"`` reproduces the reference, whose ``jax.vmap`` over an un-batched simulator key
     (vec_env.py:75-77) hands all envs the same gamete keys;
-  * ``sync_rewards=False`` returns the reward vector as a device array and so never blocks.
+  * ``sync_rewards=False`` returns the reward vector as a device array and so never blocks;
+  * ``storage="bits"`` keeps the populations between steps as bit-plane rows (1 bit per allele, 8x
+    less HBM and 8x less to read per cross).  The observation handed out
+    is unchanged -- the same launch also writes the byte-layout offspring -- unless
+    ``observations="lazy"``, which returns a ``PackedPopulation`` handle that expands on demand
+    (``env.populations``, ``np.asarray(obs)``), for policies that only look at ``infos["GEBV"]``.
 """
 from pathlib import Path
 from typing import Optional, Tuple, Union
@@ -23,7 +28,7 @@ import numpy as np
 import torch
 
 from .. import _lib, rng, spaces
-from ..engine import DeviceArray
+from ..engine import DeviceArray, PackedPopulation
 from ..simulator import Simulator
 from ..utils.paths import DATA_PATH
 
@@ -49,10 +54,20 @@ class VecBreedGym(_VectorEnvBase):
         reward_shaping: bool = False,
         env_rng: str = "shared",
         sync_rewards: bool = True,
+        storage: str = "bytes",
+        observations: str = "eager",
         **kwargs,
     ):
         if env_rng not in ("shared", "independent"):
             raise ValueError("env_rng must be 'shared' or 'independent'")
+        if storage not in ("bytes", "bits"):
+            raise ValueError("storage must be 'bytes' or 'bits'")
+        if observations not in ("eager", "lazy"):
+            raise ValueError("observations must be 'eager' or 'lazy'")
+        if observations == "lazy" and storage != "bits":
+            raise ValueError("observations='lazy' needs storage='bits'")
+        self.storage = storage
+        self.observations = observations
         self.num_envs = num_envs
         self.num_generations = num_generations
         self.autoreset = autoreset
@@ -82,7 +97,9 @@ class VecBreedGym(_VectorEnvBase):
         )
 
         self._populations = None
-        self._rows = None  # (E * n, pitch) uint8 rows behind `populations`
+        self._brows = None  # (E * n, pitch) uint8 rows behind `populations`
+        self._prows = None  # storage="bits": (E * n, packed_pitch) bit-plane rows, the state between steps
+        self._germ_prows = None
         self._n = None
         self.step_idx = None
         self.reset_infos = {}
@@ -90,24 +107,37 @@ class VecBreedGym(_VectorEnvBase):
 
     # ---- helpers -----------------------------------------------------------------------------
     @property
+    def _rows(self):
+        """The byte-layout rows of the current populations (expanded from the bit planes if need be)."""
+        if self._brows is None and self._prows is not None:
+            self._brows = self.simulator.engine.unpack(self._prows)
+        return self._brows
+
+    @property
     def populations(self):
+        if self._populations is None and self._rows is not None:
+            self._populations = self.simulator.engine.as_genotypes(self._brows, self.num_envs, self._n)
         return self._populations
 
     @populations.setter
     def populations(self, value):
         # wrappers assign fresh populations (breeding_programs_env.py:56): adopt their rows
         if value is None:
-            self._populations, self._rows, self._n = None, None, None
+            self._populations, self._brows, self._prows, self._n = None, None, None, None
             return
         rows, lead = self.simulator._rows_of(value)
         if len(lead) != 2 or lead[0] != self.num_envs:
             raise ValueError(f"populations must have shape ({self.num_envs}, n, M, 2)")
-        self._rows, self._n = rows, lead[1]
-        self._populations = self.simulator.engine.as_genotypes(rows, *lead)
+        self._adopt(rows, lead[1], self.simulator.engine.pack(rows) if self.storage == "bits" else None)
 
-    def _adopt(self, rows, n):
-        self._rows, self._n = rows, n
-        self._populations = self.simulator.engine.as_genotypes(rows, self.num_envs, n)
+    def _adopt(self, rows, n, packed=None):
+        self._brows, self._prows, self._n = rows, packed, n
+        self._populations = None if rows is None else self.simulator.engine.as_genotypes(rows, self.num_envs, n)
+
+    def _observation(self):
+        if self.observations == "lazy":
+            return PackedPopulation(self.simulator.engine, self._prows, (self.num_envs, self._n))
+        return self.populations
 
     def _device_actions(self, actions) -> torch.Tensor:
         eng = self.simulator.engine
@@ -143,18 +173,25 @@ class VecBreedGym(_VectorEnvBase):
 
     # ---- gymnasium surface -------------------------------------------------------------------
     def step(self, actions) -> Tuple[DeviceArray, np.ndarray, np.ndarray, np.ndarray, dict]:
-        if self._rows is None:
+        if self._n is None:
             raise RuntimeError("call reset() before step()")
         eng = self.simulator.engine
         idx = self._device_actions(actions)
         E, n_pool, n_out = self.num_envs, self._n, idx.shape[1]
-        out = eng.empty_population(E * n_out)
         gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
         done = self.step_idx + 1 == self.num_generations
         # the reward (max GEBV per env, vec_env.py:96-98) comes out of the same launch when it is due
         rew_dev = eng.empty((E,), torch.float32) if (self.reward_shaping or done) else None
-        self.simulator.cross_indexed(self._rows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev)
-        self._adopt(out, n_out)
+        if self.storage == "bits":
+            outp = eng.empty_packed(E * n_out)
+            out = eng.empty_population(E * n_out) if self.observations == "eager" else None
+            self.simulator.cross_indexed_packed(self._prows, E, n_pool, idx, n_out, outp, out, gebv, self._rng_mode,
+                                                rew_dev)
+            self._adopt(out, n_out, outp)
+        else:
+            out = eng.empty_population(E * n_out)
+            self.simulator.cross_indexed(self._brows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev)
+            self._adopt(out, n_out)
         self.step_idx += 1
 
         infos = {"GEBV": DeviceArray.wrap(gebv)}
@@ -170,7 +207,7 @@ class VecBreedGym(_VectorEnvBase):
 
         terminated = np.full(self.num_envs, False)
         truncated = np.full(self.num_envs, done)
-        return self.populations, rews, terminated, truncated, infos
+        return self._observation(), rews, terminated, truncated, infos
 
     def reset(self, seed: Optional[int] = None, options: Optional[dict] = None) -> Tuple[DeviceArray, dict]:
         self.step_idx = 0
@@ -187,14 +224,27 @@ class VecBreedGym(_VectorEnvBase):
         eng = self.simulator.engine
         E, n = self.num_envs, self.individual_per_gen
         idx, self.random_key = eng.founders(self.random_key, E, len(self.germplasm), n)
-        rows = eng.empty_population(E * n)
         gebv = eng.empty((E, n, eng.n_traits), torch.float32)
-        eng.gather(self._germ_rows, idx, rows, gebv)
-        self._adopt(rows, n)
+        if self.storage == "bits":
+            if self._germ_prows is None:
+                self._germ_prows = eng.pack(self._germ_rows)
+            prows = eng.empty_packed(E * n)
+            rows = eng.empty_population(E * n) if self.observations == "eager" else None
+            eng.gather_packed(self._germ_prows, idx, E * n, prows, rows, gebv)
+            self._adopt(rows, n, prows)
+        else:
+            rows = eng.empty_population(E * n)
+            eng.gather(self._germ_rows, idx, rows, gebv)
+            self._adopt(rows, n)
         self.reset_infos = {"GEBV": DeviceArray.wrap(gebv)}
-        return self.populations, self.reset_infos
+        return self._observation(), self.reset_infos
 
     def get_info(self) -> dict:
+        if self._brows is None and self._prows is not None:  # GEBV straight from the bit planes
+            eng = self.simulator.engine
+            gebv = eng.empty((self.num_envs, self._n, eng.n_traits), torch.float32)
+            eng.gather_packed(self._prows, None, self.num_envs * self._n, None, None, gebv)
+            return {"GEBV": DeviceArray.wrap(gebv)}
         return {"GEBV": self.simulator.GEBV_model(self.populations)}
 
     def set_attr(self, name, values):

@@ -144,6 +144,29 @@ int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64
 int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
                          int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
 
+/* ---- bit-plane storage behind the byte-layout API ------------
+ * The observation format of the reference stays what it is -- (rows, M, 2) one byte per allele
+ * (vec_env.py:57-62) -- but a population a VecBreedGym keeps between steps can live packed, 1 bit
+ * per allele: a packed row is uint16 P[bh_packed_pitch() / 2]; P[v] holds markers 8v .. 8v+7, low
+ * byte = allele-0 bits, high byte = allele-1 bits (bit t = marker 8v + t), zero beyond M.
+ * A step then reads M/2 bytes of parents per cross instead of 4M, and still hands out the same
+ * byte-layout offspring when asked to. */
+int64_t bh_packed_pitch(const bh_ctx *ctx);
+/* byte-layout rows (n_rows, pitch) -> packed rows (n_rows, packed_pitch); bit 0 of each byte counts. */
+int bh_pack(bh_ctx *ctx, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed);
+/* bh_cross on a packed pool (vec_env.py:88-91,132-134 like bh_cross).  d_out_packed (n_envs, n_out,
+ * packed_pitch) receives the offspring; d_out_bytes, unless NULL, receives the same offspring in
+ * the byte layout (n_envs, n_out, pitch) -- the observation `step` returns.  Same key chain, same
+ * masks, same offspring as bh_cross on the unpacked pool. */
+int bh_cross_packed(bh_ctx *ctx, const uint16_t *d_pool, int64_t n_envs, int64_t pool_rows,
+                    const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
+                    uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv, float *d_reward);
+/* bh_gather on packed rows (vec_env.py:126-129).  d_idx NULL = rows 0..n_rows-1 in order, which
+ * makes this the unpack (d_out_bytes only) and the GEBV of packed rows (d_gebv only).  Any of
+ * d_out_packed, d_out_bytes, d_gebv may be NULL. */
+int bh_gather_packed(bh_ctx *ctx, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
+                     int64_t n_rows, uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv);
+
 /* ---- host-side RNG plumbing (JAX threefry key chains) -------------------------------- */
 /* jax.random.key(seed) (vec_env.py:115, Simulator.set_seed). */
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]);

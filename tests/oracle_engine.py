@@ -19,6 +19,7 @@ class OracleEngine(EngineBase):
         self.effects = eff if eff.ndim == 2 else eff[:, None]
         self.n_markers, self.n_traits = self.effects.shape
         self.pitch = (2 * self.n_markers + 15) // 16 * 16
+        self.packed_pitch = 16 * ((self.n_markers + 63) // 64)
         self.calls = {"cross": 0, "gather": 0, "gebv": 0, "reward_max": 0, "topk": 0}
 
     def _g(self, rows_t):  # (rows, pitch) -> (rows, M, 2) numpy u8
@@ -55,6 +56,56 @@ class OracleEngine(EngineBase):
         out[: len(i)] = src[torch.from_numpy(i)]
         if gebv is not None:
             gebv.reshape(-1, self.n_traits)[: len(i)] = torch.from_numpy(co.gebv(self._g(out[: len(i)]), self.effects))
+
+    # ---- bit-plane rows (layout documented in include/breedhip.h) ------------------------------
+    def _pack_np(self, g):  # (rows, M, 2) u8 -> (rows, packed_pitch) u8
+        rows, M = g.shape[0], self.n_markers
+        nw = (M + 63) // 64
+        bits = np.zeros((rows, nw * 64, 2), np.uint8)
+        bits[:, :M] = g & 1
+        by = np.packbits(bits.reshape(rows, nw * 8, 8, 2), axis=2, bitorder="little")[:, :, 0, :]
+        return np.ascontiguousarray(by).reshape(rows, nw * 16)  # (allele-0 byte, allele-1 byte) per 8 markers
+
+    def _unpack_np(self, p):  # (rows, packed_pitch) u8 -> (rows, M, 2) u8
+        rows = p.shape[0]
+        by = p.reshape(rows, -1, 1, 2)
+        bits = np.unpackbits(by, axis=2, count=8, bitorder="little")  # (rows, nvp, 8, 2)
+        return np.ascontiguousarray(bits.reshape(rows, -1, 2)[:, : self.n_markers])
+
+    def _put_bytes(self, out, g):
+        out[: g.shape[0]] = 0
+        out[: g.shape[0], : 2 * self.n_markers] = torch.from_numpy(g.reshape(g.shape[0], -1))
+
+    def pack(self, rows_t, out=None):
+        p = torch.from_numpy(self._pack_np(self._g(rows_t)))
+        if out is not None:
+            out[: p.shape[0]] = p
+            return out
+        return p
+
+    def unpack(self, packed, out=None):
+        if out is None:
+            out = self.empty_population(packed.shape[0])
+        self._put_bytes(out, self._unpack_np(packed.numpy()))
+        return out
+
+    def cross_packed(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes=None, gebv=None,
+                     reward=None):
+        tmp = self.empty_population(n_envs * n_out)
+        self.cross(self.unpack(pool[: n_envs * pool_rows]), n_envs, pool_rows, idx, n_out, key, rng_mode, tmp, gebv, reward)
+        out_packed[: n_envs * n_out] = self.pack(tmp)
+        if out_bytes is not None:
+            out_bytes[: n_envs * n_out] = tmp
+
+    def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None):
+        if idx is None:
+            idx = torch.arange(n_rows, dtype=torch.int32)
+        tmp = self.empty_population(n_rows)
+        self.gather(self.unpack(src), idx, tmp, gebv)
+        if out_packed is not None:
+            out_packed[:n_rows] = self.pack(tmp)
+        if out_bytes is not None:
+            out_bytes[:n_rows] = tmp
 
     def gebv(self, pop, out=None):
         self.calls["gebv"] += 1

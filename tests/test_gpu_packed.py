@@ -1,0 +1,274 @@
+"""GPU: bit-plane (1 bit per allele) rows through the C ABI -- pack / unpack, the packed cross and
+gather against the CPU oracle and against the byte-layout kernels: bit-exact genotypes, GEBV within
+1e-5, identical key chains."""
+import numpy as np
+import pytest
+import torch
+from golden_util import CASES, load_case
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+GEBV_RTOL = 1e-5
+
+
+def make_engine(r, eff):
+    from breedgym_amd import HipEngine
+
+    return HipEngine(r, eff)
+
+
+def gebv_close(got, ref64):
+    scale = np.maximum(np.abs(ref64), 1.0)
+    return np.all(np.abs(got.astype(np.float64) - ref64) <= GEBV_RTOL * scale)
+
+
+def pack_numpy(g):
+    """(rows, M, 2) 0/1 -> (rows, 8 * nw) uint16 in the documented layout (include/breedhip.h)."""
+    rows, M, _ = g.shape
+    nw = (M + 63) // 64
+    bits = np.zeros((rows, nw * 64, 2), np.uint8)
+    bits[:, :M] = g
+    by = np.packbits(bits.reshape(rows, nw * 8, 8, 2), axis=2, bitorder="little")[:, :, 0, :]  # (rows, nvp, 2)
+    return by[..., 0].astype(np.uint16) | (by[..., 1].astype(np.uint16) << 8)
+
+
+def packed_host(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("M", [1, 5, 8, 9, 63, 64, 65, 100, 1000, 1001, 10000, 20000])
+def test_pack_unpack_roundtrip(M, rng):
+    N = 7
+    g = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)
+    eng = make_engine(np.full(M, 0.01, np.float32), np.ones((M, 1), np.float32))
+    rows = eng.upload_population(g)
+    pk = eng.pack(rows)
+    assert pk.shape == (N, eng.packed_pitch) and eng.packed_pitch == 16 * ((M + 63) // 64)
+    assert np.array_equal(packed_host(pk), pack_numpy(g))
+    back = eng.unpack(pk)
+    assert np.array_equal(eng.download_population(back).view(np.uint8), g)
+    # the padding of the byte rows is zero too (they are read 16 bytes at a time)
+    assert np.array_equal(back.cpu().numpy()[:, 2 * M:], np.zeros((N, eng.pitch - 2 * M), np.uint8))
+
+
+def run_packed_cross(eng, pool, idx, seed, mode, want_bytes=True, want_gebv=True, reward=False):
+    E, n_pool, M, _ = pool.shape
+    n_out = idx.shape[1]
+    ppool = eng.pack(eng.upload_population(pool.reshape(E * n_pool, M, 2)))
+    outp = eng.empty_packed(E * n_out)
+    outb = eng.empty_population(E * n_out) if want_bytes else None
+    gebv = eng.empty((E, n_out, eng.n_traits), torch.float32) if want_gebv else None
+    rew = eng.empty((E,), torch.float32) if reward else None
+    key = co.key_from_seed(seed).copy()
+    eng.cross_packed(ppool, E, n_pool, torch.from_numpy(idx).to(eng.device), n_out, key, mode, outp, outb, gebv, rew)
+    got_b = eng.download_population(outb).view(np.uint8).reshape(E, n_out, M, 2) if want_bytes else None
+    return packed_host(outp), got_b, key, (gebv.cpu().numpy() if want_gebv else None), (
+        rew.cpu().numpy() if reward else None)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_fixtures_packed(name):
+    c = load_case(name)
+    eng = make_engine(c["r"], c["effects"])
+    pk, got, key, g, _ = run_packed_cross(eng, c["pool"], c["idx"], c["seed"], c["rng_mode"])
+    assert np.array_equal(got, c["out"]), "byte-layout offspring differ from the golden fixture"
+    E, n_out, M, _ = c["out"].shape
+    assert np.array_equal(pk, pack_numpy(c["out"].reshape(E * n_out, M, 2)))
+    assert np.array_equal(key, c["new_key"])
+    assert gebv_close(g, c["gebv64"])
+
+
+@pytest.mark.parametrize("M", [1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 1000, 1001, 4999, 10000])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_packed_cross_vs_oracle(M, mode, rng):
+    E, NP, NO, T = 3, 11, 13, 2
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    idx = rng.integers(-NP, NP + 2, (E, NO, 2), dtype=np.int32)
+    r = (rng.random(M) * 0.05).astype(np.float32)
+    r[:: max(1, M // 5)] = 0.5
+    r[rng.random(M) < 0.16] = 0.0
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    seed = int(rng.integers(0, 2**32))
+    eng = make_engine(r, eff)
+    want_bytes = (M + mode) % 2 == 0  # with and without the byte-layout observation
+    pk, got, key, g, rew = run_packed_cross(eng, pool, idx, seed, mode, want_bytes=want_bytes, reward=True)
+    ref, refkey = co.cross(pool, idx, r, co.key_from_seed(seed), mode)
+    if want_bytes:
+        assert np.array_equal(got, ref), f"M={M} mode={mode}: {np.argwhere(got != ref)[:5]}"
+    assert np.array_equal(pk, pack_numpy(ref.reshape(E * NO, M, 2)))
+    assert np.array_equal(key, refkey)
+    _, g64 = co.gebv(ref, eff, want64=True)
+    assert gebv_close(g, g64)
+    assert np.array_equal(rew, g.reshape(E, -1).max(axis=1))
+
+
+@pytest.mark.parametrize("M", [16392, 50001])
+def test_packed_cross_long_rows(M, rng):
+    E, NP, NO = 2, 5, 6
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    idx = rng.integers(0, NP, (E, NO, 2), dtype=np.int32)
+    r = (rng.random(M) * 0.002).astype(np.float32)
+    r[:: M // 7] = 0.5
+    eff = rng.laplace(0, 6, (M, 3)).astype(np.float32)
+    eng = make_engine(r, eff)
+    for mode in (0, 1):
+        pk, got, key, g, _ = run_packed_cross(eng, pool, idx, 42, mode)
+        ref, refkey = co.cross(pool, idx, r, co.key_from_seed(42), mode)
+        assert np.array_equal(got, ref) and np.array_equal(key, refkey)
+        assert np.array_equal(pk, pack_numpy(ref.reshape(E * NO, M, 2)))
+        assert gebv_close(g, co.gebv(ref, eff, want64=True)[1])
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 8, 9, 17])
+@pytest.mark.parametrize("want_bytes", [False, True])
+def test_packed_traits(T, want_bytes, rng):
+    """fused f64 GEBV (T <= 8), matrix-core pass over the byte rows (T >= 3 with observations),
+    chained f64 passes over the packed rows (T > 8 without)."""
+    M, N, NO = 1000, 40, 37
+    pop = rng.integers(0, 2, (1, N, M, 2), dtype=np.uint8)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eff[3, 0] = 475.0
+    eng = make_engine(np.full(M, 0.01, np.float32), eff)
+    idx = rng.integers(0, N, (1, NO, 2), dtype=np.int32)
+    pk, got, _, g, _ = run_packed_cross(eng, pop, idx, 3, 0, want_bytes=want_bytes)
+    ref, _ = co.cross(pop, idx, np.full(M, 0.01, np.float32), co.key_from_seed(3), 0)
+    assert np.array_equal(pk, pack_numpy(ref.reshape(NO, M, 2)))
+    assert gebv_close(g[0], co.gebv(ref[0], eff, want64=True)[1])
+    # gather + GEBV through an index, and GEBV of packed rows in place
+    ppool = eng.pack(eng.upload_population(pop[0]))
+    gi = torch.from_numpy(rng.integers(-N, N + 2, 33, dtype=np.int32)).to(eng.device)
+    outp = eng.empty_packed(33)
+    outb = eng.empty_population(33) if want_bytes else None
+    gg = eng.empty((33, T), torch.float32)
+    eng.gather_packed(ppool, gi, 33, outp, outb, gg)
+    ii = gi.cpu().numpy().astype(np.int64)
+    ii = np.clip(np.where(ii < 0, ii + N, ii), 0, N - 1)
+    sel = pop[0][ii]
+    assert np.array_equal(packed_host(outp), pack_numpy(sel))
+    if want_bytes:
+        assert np.array_equal(eng.download_population(outb).view(np.uint8), sel)
+    assert gebv_close(gg.cpu().numpy(), co.gebv(sel, eff, want64=True)[1])
+    g2 = eng.empty((N, T), torch.float32)
+    eng.gather_packed(ppool, None, N, None, None, g2)
+    assert gebv_close(g2.cpu().numpy(), co.gebv(pop[0], eff, want64=True)[1])
+
+
+def test_packed_equals_byte_path_over_generations(rng):
+    """Ten generations, both layouts side by side from the same seed: same offspring, same keys, with
+    the run-ahead masks of one layout's launches feeding the next call of the same layout."""
+    E, n, M, T = 4, 64, 1500, 1
+    r = (rng.random(M) * 0.01).astype(np.float32)
+    r[::300] = 0.5
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eng_b, eng_p = make_engine(r, eff), make_engine(r, eff)
+    pop = rng.integers(0, 2, (E * n, M, 2), dtype=np.uint8)
+    rows_b = eng_b.upload_population(pop)
+    rows_p = eng_p.pack(eng_p.upload_population(pop))
+    kb, kp = co.key_from_seed(9).copy(), co.key_from_seed(9).copy()
+    for gen in range(10):
+        idx = torch.from_numpy(rng.integers(0, n, (E, n, 2), dtype=np.int32)).cuda()
+        out_b = eng_b.empty_population(E * n)
+        gb = eng_b.empty((E, n, T), torch.float32)
+        eng_b.cross(rows_b, E, n, idx, n, kb, gen % 2, out_b, gb)
+        out_p, obs = eng_p.empty_packed(E * n), eng_p.empty_population(E * n)
+        gp = eng_p.empty((E, n, T), torch.float32)
+        eng_p.cross_packed(rows_p, E, n, idx, n, kp, gen % 2, out_p, obs, gp)
+        assert torch.equal(obs, out_b) and np.array_equal(kb, kp)
+        assert torch.equal(eng_p.unpack(out_p), out_b)
+        assert torch.allclose(gb, gp, rtol=1e-6, atol=1e-4)
+        rows_b, rows_p = out_b, out_p
+
+
+def test_packed_errors_and_empty(rng):
+    M = 100
+    eng = make_engine(np.full(M, 0.01, np.float32), np.ones((M, 1), np.float32))
+    pk = eng.pack(eng.upload_population(rng.integers(0, 2, (4, M, 2), dtype=np.uint8)))
+    key = co.key_from_seed(0).copy()
+    idx = torch.zeros((1, 2, 2), dtype=torch.int32, device=eng.device)
+    with pytest.raises(ValueError):  # output aliases the pool
+        eng.cross_packed(pk, 1, 4, idx, 2, key, 0, pk)
+    with pytest.raises(ValueError):
+        eng.cross_packed(pk, 1, 4, idx, 2, key, 7, eng.empty_packed(2))
+    # zero crosses: the key still advances like split(key, 1)[0]
+    k0 = key.copy()
+    eng.cross_packed(pk, 1, 4, torch.zeros((1, 0, 2), dtype=torch.int32, device=eng.device), 0, key, 0,
+                     eng.empty_packed(1))
+    assert np.array_equal(key, co.split(k0, 1)[0])
+    with pytest.raises(ValueError):  # identity gather of more rows than there are
+        eng.gather_packed(pk, None, 5, eng.empty_packed(5))
+
+
+def test_packed_full_size_properties():
+    """BASELINE configs[1] size: closure and agreement with the byte-layout kernel on device."""
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    gm = synthetic_genetic_map(10_000)
+    E, n, M = 16, 256, 10_000
+    g = synthetic_genotypes(370, M)
+    rng = np.random.default_rng(5)
+    from breedgym_amd import Simulator
+
+    sim = Simulator(genetic_map=gm, seed=0)
+    eng = sim.engine
+    founders = torch.from_numpy(rng.integers(0, 370, E * n, dtype=np.int32)).cuda()
+    germ = eng.upload_population(g)
+    rows = eng.empty_population(E * n)
+    eng.gather(germ, founders, rows)
+    prow = eng.empty_packed(E * n)
+    obs0 = eng.empty_population(E * n)
+    eng.gather_packed(eng.pack(germ), founders, E * n, prow, obs0)
+    assert torch.equal(obs0, rows)
+    idx = torch.from_numpy(rng.integers(0, n, (E, n, 2), dtype=np.int32)).cuda()
+    for mode in (0, 1):
+        kb, kp = co.key_from_seed(1).copy(), co.key_from_seed(1).copy()
+        out_b, gb = eng.empty_population(E * n), eng.empty((E, n, 1), torch.float32)
+        eng.cross(rows, E, n, idx, n, kb, mode, out_b, gb)
+        out_p, obs, gp = eng.empty_packed(E * n), eng.empty_population(E * n), eng.empty((E, n, 1), torch.float32)
+        rw = eng.empty((E,), torch.float32)
+        eng.cross_packed(prow, E, n, idx, n, kp, mode, out_p, obs, gp, rw)
+        assert torch.equal(obs, out_b) and np.array_equal(kb, kp)
+        assert torch.equal(eng.pack(out_b), out_p)
+        assert torch.allclose(gb, gp, rtol=1e-6, atol=1e-4)
+        assert torch.equal(rw, gp.reshape(E, -1).max(dim=1).values)
+
+
+@pytest.mark.parametrize("observations", ["eager", "lazy"])
+@pytest.mark.parametrize("env_rng", ["shared", "independent"])
+def test_vec_env_bit_plane_storage(observations, env_rng):
+    """VecBreedGym(storage="bits") against the byte-layout env on the device: two horizons with
+    autoreset, a population-size change, a wrapper that assigns populations, GEBV straight from bits."""
+    from breedgym_amd import PackedPopulation, VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector import SelectionScores
+
+    gm = synthetic_genetic_map(1300, n_chr=4, n_traits=2, seed=3)
+    geno = synthetic_genotypes(50, 1300, seed=4)
+    kw = dict(num_envs=5, initial_population=geno, genetic_map=gm, individual_per_gen=24, num_generations=4,
+              reward_shaping=True, env_rng=env_rng)
+    ref = VecBreedGym(**kw)
+    env = VecBreedGym(storage="bits", observations=observations, **kw)
+    p0, i0 = ref.reset(seed=5)
+    p1, i1 = env.reset(seed=5)
+    assert isinstance(p1, PackedPopulation) == (observations == "lazy")
+    assert np.array_equal(np.asarray(p1), np.asarray(p0)) and torch.equal(i0["GEBV"], i1["GEBV"])
+    rng = np.random.default_rng(1)
+    for step in range(9):
+        a = rng.integers(0, 24, (5, 24 if step != 5 else 17, 2)).astype(np.int32)
+        o0, r0, _, t0, f0 = ref.step(a)
+        o1, r1, _, t1, f1 = env.step(a)
+        assert np.array_equal(np.asarray(o1), np.asarray(o0))
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+        assert torch.allclose(f0["GEBV"].as_subclass(torch.Tensor), f1["GEBV"].as_subclass(torch.Tensor), rtol=1e-6, atol=1e-4)
+        assert torch.allclose(env.get_info()["GEBV"].as_subclass(torch.Tensor),
+                              ref.get_info()["GEBV"].as_subclass(torch.Tensor), rtol=1e-6, atol=1e-4)
+        assert np.array_equal(env.simulator.random_key, ref.simulator.random_key)
+    w0, w1 = SelectionScores(ref, k=6), SelectionScores(env, k=6)
+    w0.reset(seed=2)
+    w1.reset(seed=2)
+    for _ in range(3):
+        s = ref.get_info()["GEBV"][..., 0]
+        o0 = w0.step(s)[0]
+        o1 = w1.step(s)[0]
+        assert np.array_equal(np.asarray(o1), np.asarray(o0))

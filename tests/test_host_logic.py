@@ -386,3 +386,39 @@ def test_simplified_and_kbest_env(data):  # reference tests/test_wrappers.py:7-7
     for _ in range(5):
         o, *_ = kb2.step(6)
     assert np.mean(o["GEBV"]) > np.mean(o0["GEBV"])
+
+
+@pytest.mark.parametrize("observations", ["eager", "lazy"])
+@pytest.mark.parametrize("env_rng", ["shared", "independent"])
+def test_vec_bit_plane_storage_is_invisible(data, observations, env_rng):
+    """storage="bits" (SURVEY section 8f, N4): same trajectories as the byte layout, step for step --
+    observations, GEBV, rewards, key chains, autoreset -- with eager and with on-demand observations."""
+    from breedgym_amd import PackedPopulation
+
+    kw = dict(num_envs=3, individual_per_gen=10, num_generations=4, reward_shaping=True, env_rng=env_rng)
+    ref = make_vec(data, **kw)
+    env = make_vec(data, storage="bits", observations=observations, **kw)
+    p0, i0 = ref.reset(seed=11)
+    p1, i1 = env.reset(seed=11)
+    assert p1.shape == p0.shape and np.array_equal(np.asarray(p1), np.asarray(p0))
+    assert np.array_equal(np.asarray(i1["GEBV"]), np.asarray(i0["GEBV"]))
+    assert isinstance(p1, PackedPopulation) == (observations == "lazy")
+    rng = np.random.default_rng(0)
+    for step in range(9):  # two horizons: autoreset included
+        a = rng.integers(0, 10, (3, 10 if step != 2 else 6, 2)).astype(np.int32)  # step 2 shrinks the population
+        o0, r0, _, t0, f0 = ref.step(a)
+        o1, r1, _, t1, f1 = env.step(a)
+        assert np.array_equal(np.asarray(o1), np.asarray(o0)) and o1.shape == o0.shape
+        assert np.array_equal(r0, r1) and np.array_equal(t0, t1)
+        assert np.array_equal(np.asarray(f0["GEBV"]), np.asarray(f1["GEBV"]))
+        assert np.array_equal(np.asarray(env.populations), np.asarray(ref.populations))
+        assert np.array_equal(np.asarray(env.get_info()["GEBV"]), np.asarray(ref.get_info()["GEBV"]))
+        assert np.array_equal(env.simulator.random_key, ref.simulator.random_key)
+    # wrappers that assign populations keep working: the bit planes follow the assignment
+    env.populations = ref.populations
+    a = rng.integers(0, 10, (3, 10, 2)).astype(np.int32)
+    assert np.array_equal(np.asarray(env.step(a)[0]), np.asarray(ref.step(a)[0]))
+    with pytest.raises(ValueError):
+        make_vec(data, observations="lazy")
+    with pytest.raises(ValueError):
+        make_vec(data, storage="nibbles")

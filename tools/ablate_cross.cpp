@@ -8,7 +8,8 @@
 #include "breedhip.h"
 
 int main(int argc, char **argv) {
-  const int64_t M = argc > 1 ? atoll(argv[1]) : 10000, E = argc > 2 ? atoll(argv[2]) : 16, n = argc > 3 ? atoll(argv[3]) : 256;
+  const int mode = argc > 1 ? atoi(argv[1]) : 0;
+  const int64_t M = argc > 2 ? atoll(argv[2]) : 10000, E = argc > 3 ? atoll(argv[3]) : 16, n = argc > 4 ? atoll(argv[4]) : 256;
   const int reps = 50;
   std::vector<float> r(M, 0.0015f), eff(M, 1.0f);
   for (int64_t m = 0; m < M; m += M / 10) r[m] = 0.5f;
@@ -23,13 +24,13 @@ int main(int argc, char **argv) {
   bh_memcpy_h2d(ctx, pool, h.data(), h.size()); bh_memcpy_h2d(ctx, idx, hi.data(), hi.size() * 4); bh_sync(ctx);
   uint32_t key[2] = {0, 7};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) bh_cross(ctx, pool, E, n, idx, n, key, 1, out, gebv);
+  for (int i = 0; i < 5; ++i) bh_cross(ctx, pool, E, n, idx, n, key, mode, out, gebv, nullptr);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int i = 0; i < reps; ++i) bh_cross(ctx, i & 1 ? out : pool, E, n, idx, n, key, 1, i & 1 ? pool : out, gebv);
+  for (int i = 0; i < reps; ++i) bh_cross(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, gebv, nullptr);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("M=%lld C=%lld : %.1f us per launch, %.1f M crosses/s, %.0f GB/s algorithmic\n", (long long)M, (long long)rows,
+  printf("byte layout mode=%d M=%lld C=%lld : %.1f us per launch, %.1f M crosses/s, %.0f GB/s algorithmic\n", mode, (long long)M, (long long)rows,
          ms / reps * 1e3, rows / (ms / reps * 1e-3) / 1e6, 6.0 * M * rows / (ms / reps * 1e-3) / 1e9);
   return 0;
 }
