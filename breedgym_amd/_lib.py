@@ -12,7 +12,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 LIB_PATH = _PKG / "libbreedhip.so"
-_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "select_kernels.h", "gebv_mfma.h", "threefry.h")] + [
+_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "index_kernels.h", "select_kernels.h", "gebv_mfma.h", "threefry.h")] + [
     _ROOT / "include" / "breedhip.h"
 ]
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     "bh_reward_max": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "bh_topk": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "bh_selection_actions": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _u32p, _vp]),
+    "bh_optimal_haploid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "bh_packed_pitch": (_i64, [_vp]),
     "bh_pack": (_int, [_vp, _vp, _i64, _vp]),
     "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp]),

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "gebv_mfma.h"
+#include "index_kernels.h"
 #include "packed_kernels.h"
 #include "row_kernels.h"
 #include "select_kernels.h"
@@ -57,7 +58,8 @@ struct bh_ctx {
   uint32_t *d_ctrB = nullptr;                     // second Threefry counter per pair
   uint64_t *d_alwA = nullptr, *d_alwB = nullptr;  // site words of markers with r >= 1, or null
   int64_t nthr = 0;
-  double *d_eff = nullptr;  // (T, effPitch)
+  double *d_eff = nullptr;     // (T, effPitch)
+  double *d_effsum = nullptr;  // (effPitch) sum over traits (block values of the optimal haploid)
   // crossover-mask buffers: the launch that streams generation g from d_Z[cur] also makes the
   // masks of generation g+1 in d_Z[1 - cur] (cross_kernel's two roles)
   uint8_t *d_Z[2] = {nullptr, nullptr};
@@ -504,6 +506,13 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
     BH_HIP_C(hipMemcpy(c->d_alwB, alwB.data(), alwB.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   BH_HIP_C(hipMemcpy(c->d_eff, eff.data(), eff.size() * sizeof(double), hipMemcpyHostToDevice));
+  {
+    std::vector<double> effsum((size_t)c->effPitch, 0.0);
+    for (int64_t m = 0; m < n_markers; ++m)
+      for (int64_t t = 0; t < n_traits; ++t) effsum[(size_t)m] += (double)effects[m * n_traits + t];
+    BH_HIP_C(hipMalloc(&c->d_effsum, effsum.size() * sizeof(double)));
+    BH_HIP_C(hipMemcpy(c->d_effsum, effsum.data(), effsum.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   // ---- fixed-point effects for the MFMA GEBV (gebv_mfma.h): 6 balanced base-256 digits of
   //      round(eff * 2^s_t), s_t the largest shift that keeps |.| <= 2^46
   if (n_traits > 0) {
@@ -569,6 +578,7 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
+  if (c->d_effsum) (void)hipFree(c->d_effsum);
   for (int i = 0; i < 2; ++i) {
     if (c->d_cand_s[i]) (void)hipFree(c->d_cand_s[i]);
     if (c->d_cand_i[i]) (void)hipFree(c->d_cand_i[i]);
@@ -899,6 +909,38 @@ int bh_gebv(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
   if (!d_pop || !d_gebv) return fail(BH_ERR_BAD_ARG, "bh_gebv: null device pointer");
   if (rows > 0x3FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_gebv: too many rows");
   return gebv_chunks(c, d_pop, rows, d_gebv, 0);
+}
+
+int bh_optimal_haploid(bh_ctx *c, const uint8_t *d_pop, int64_t n_rows, const int32_t *d_block_start,
+                       int64_t n_blocks, uint8_t *d_ohp, float *d_ohv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0 || n_blocks < 0) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: negative size");
+  if (n_rows == 0) return BH_OK;
+  if (!d_pop || (!d_ohp && !d_ohv)) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: null device pointer");
+  if (n_blocks > 0 && !d_block_start) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: blocks without offsets");
+  if (c->T == 0) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: the context has no traits");
+  if (n_rows > 0x3FFFFFFF || n_blocks > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_optimal_haploid: too large");
+  for (int t0 = 0; t0 < c->T; t0 += bh::kOhvTraits) {
+    bh::OhvParams p{};
+    p.pop = d_pop;
+    p.eff = c->d_eff;
+    p.effsum = c->d_effsum;
+    p.block_start = d_block_start;
+    p.ohp = d_ohp;
+    p.ohv = d_ohv;
+    p.pitch = c->pitch;
+    p.effPitch = c->effPitch;
+    p.M = (int32_t)c->M;
+    p.T = (int32_t)c->T;
+    p.t0 = t0;
+    p.tcount = (int32_t)std::min<int64_t>(bh::kOhvTraits, c->T - t0);
+    p.n_rows = (int32_t)n_rows;
+    p.n_blocks = (int32_t)n_blocks;
+    hipLaunchKernelGGL(bh::optimal_haploid_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+    if (!d_ohv) break;  // the haploid itself is complete after the first launch
+  }
+  return BH_OK;
 }
 
 int bh_reward_max(bh_ctx *c, const float *d_gebv, int64_t n_envs, int64_t per_env, float *d_reward) {

@@ -287,6 +287,16 @@ class HipEngine(EngineBase):
         _lib.check(self._L.bh_gebv(self._h, pop.data_ptr(), rows, out.data_ptr()))
         return out
 
+    def optimal_haploid(self, pop, block_start=None, want_pop=True, want_value=True):
+        """Optimal haploid (rows, M) uint8 and its value (rows, T) f32 of byte-layout rows (bh_optimal_haploid);
+        ``block_start``: int32 device tensor of block offsets, or None for the blockless rule."""
+        rows = pop.shape[0]
+        ohp = torch.empty((rows, self.n_markers), dtype=torch.uint8, device=self.device) if want_pop else None
+        ohv = torch.empty((rows, self.n_traits), dtype=torch.float32, device=self.device) if want_value else None
+        nb = 0 if block_start is None else block_start.numel() - 1
+        _lib.check(self._L.bh_optimal_haploid(self._h, pop.data_ptr(), rows, _ptr(block_start), nb, _ptr(ohp), _ptr(ohv)))
+        return ohp, ohv
+
     def reward_max(self, gebv, n_envs, out=None) -> torch.Tensor:
         if out is None:
             out = torch.empty((n_envs,), dtype=torch.float32, device=self.device)

@@ -89,16 +89,29 @@ class DistributedBreedGym:
 
 
 class ShardedPopulation:
-    """One population of ``n_total`` individuals, rows ``[rank * n_local, (rank + 1) * n_local)`` here."""
+    """One population of ``n_total`` individuals, rows ``[rank * n_local, (rank + 1) * n_local)`` here.
 
-    def __init__(self, simulator, local_rows: torch.Tensor, group=None):
+    ``storage="bits"`` keeps the shard -- and, more to the point, the winners every rank all-gathers
+    each generation -- as bit-plane rows: 8x less HBM and 8x less on the xGMI links (at BASELINE
+    config 4: 164 MB per generation instead of 1.31 GB)."""
+
+    def __init__(self, simulator, local_rows: torch.Tensor, group=None, storage: str = "bytes"):
+        if storage not in ("bytes", "bits"):
+            raise ValueError("storage must be 'bytes' or 'bits'")
         self.sim = simulator
         self.eng = simulator.engine
         self.group = group
+        self.storage = storage
         self.rank, self.world_size = _world(group)
-        self.rows = local_rows  # (n_local, pitch) uint8 on this rank's device
+        # (n_local, pitch) byte-layout rows, or (n_local, packed_pitch) bit-plane rows, on this rank's device
+        self._store = self.eng.pack(local_rows) if storage == "bits" else local_rows
         self.n_local = local_rows.shape[0]
         self.n_total = self.n_local * self.world_size
+
+    @property
+    def rows(self) -> torch.Tensor:
+        """This rank's shard in the byte layout (expanded from the bit planes if need be)."""
+        return self.eng.unpack(self._store) if self.storage == "bits" else self._store
 
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size == 1:
@@ -110,8 +123,18 @@ class ShardedPopulation:
             dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
         return out
 
+    def _gather_local(self, src, idx, out) -> None:
+        if self.storage == "bits":
+            self.eng.gather_packed(src, idx, idx.numel(), out)
+        else:
+            self.eng.gather(src, idx, out)
+
     def gebv(self) -> torch.Tensor:
-        return self.eng.gebv(self.rows)
+        if self.storage == "bits":
+            g = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
+            self.eng.gather_packed(self._store, None, self.n_local, None, None, g)
+            return g
+        return self.eng.gebv(self._store)
 
     def global_topk(self, local_scores: torch.Tensor, k: int) -> torch.Tensor:
         """Global indices (descending score, ties to the lower global index) of the k best of the
@@ -144,19 +167,23 @@ class ShardedPopulation:
         c = max(int(counts.max()), 1)
         mine = owner == self.rank
         local_idx = (global_idx - self.rank * self.n_local)[mine].to(torch.int32).contiguous()
-        send = torch.empty((c, self.rows.shape[1]), dtype=torch.uint8, device=self.rows.device)
+        send = torch.empty((c, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
         if local_idx.numel():
-            self.eng.gather(self.rows, local_idx, send[: local_idx.numel()])
+            self._gather_local(self._store, local_idx, send[: local_idx.numel()])
         if local_idx.numel() < c:
             send[local_idx.numel():].zero_()  # padding rows are never indexed; keep them valid genotypes
         pool = self._all_gather(send).reshape(W * c, -1)
         return pool, (owner * c + pos).to(torch.int32)
 
     def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
-        """The genotype rows of `global_idx` (k,), in that order, replicated on every rank."""
+        """The genotype rows of `global_idx` (k,), in that order, replicated on every rank (byte layout)."""
         pool, slot = self.replicate_winners(global_idx)
-        out = torch.empty((global_idx.numel(), pool.shape[1]), dtype=torch.uint8, device=pool.device)
-        self.eng.gather(pool, slot.contiguous(), out)
+        k = global_idx.numel()
+        out = self.eng.empty_population(k)
+        if self.storage == "bits":
+            self.eng.gather_packed(pool, slot.contiguous(), k, None, out)
+        else:
+            self.eng.gather(pool, slot.contiguous(), out)
         return out
 
     def select_and_cross(self, k: int, pairs_local: torch.Tensor, key: np.ndarray) -> DeviceArray:
@@ -166,10 +193,14 @@ class ShardedPopulation:
         scores = self.gebv()[:, 0]
         best = self.global_topk(scores, k)
         pool, slot = self.replicate_winners(best)
-        out = self.eng.empty_population(self.n_local)
         gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
         pairs = pairs_local.reshape(-1).to(device=slot.device, dtype=torch.int64)
         idx = slot[pairs].reshape(1, -1, 2).contiguous()
-        self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
-        self.rows = out
+        if self.storage == "bits":
+            out = self.eng.empty_packed(self.n_local)
+            self.eng.cross_packed(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, None, gebv)
+        else:
+            out = self.eng.empty_population(self.n_local)
+            self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
+        self._store = out
         return DeviceArray.wrap(gebv)

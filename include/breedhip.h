@@ -167,6 +167,15 @@ int bh_cross_packed(bh_ctx *ctx, const uint16_t *d_pool, int64_t n_envs, int64_t
 int bh_gather_packed(bh_ctx *ctx, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
                      int64_t n_rows, uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv);
 
+/* Selection indices of the reference (breedgym/utils/index_functions.py:21-78): the optimal haploid of
+ * every individual and its value.  d_pop (n_rows, pitch).  n_blocks == 0: marker m of the optimal
+ * haploid is any(alleles) where effects[m, 0] > 0 and all(alleles) elsewhere (:66-78); otherwise
+ * d_block_start (n_blocks + 1) int32 marker offsets on the device and, per block, the haplotype with the
+ * larger sum_m sum_t allele * effects[m, t] (the first on ties) supplies the block (:44-63).
+ * d_ohp (n_rows, M) u8 or NULL; d_ohv (n_rows, T) f32 or NULL = 2 * sum_m OHP[i,m] * effects[m,t] (:24). */
+int bh_optimal_haploid(bh_ctx *ctx, const uint8_t *d_pop, int64_t n_rows, const int32_t *d_block_start,
+                       int64_t n_blocks, uint8_t *d_ohp, float *d_ohv);
+
 /* ---- host-side RNG plumbing (JAX threefry key chains) -------------------------------- */
 /* jax.random.key(seed) (vec_env.py:115, Simulator.set_seed). */
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]);

@@ -267,6 +267,40 @@ void bo_reward_max(const float *gebv, int64_t E, int64_t nT, float *out) {
   }
 }
 
+void bo_optimal_haploid(const uint8_t *pop, int64_t n, int64_t M, const float *effects, int64_t T,
+                        const int32_t *block_start, int64_t n_blocks, uint8_t *ohp, float *ohv) {
+  uint8_t *h = (uint8_t *)malloc((size_t)(M > 0 ? M : 1));
+  for (int64_t i = 0; i < n; ++i) {
+    const uint8_t *g = pop + i * M * 2;
+    if (n_blocks == 0) {
+      for (int64_t m = 0; m < M; ++m) {
+        const int a0 = g[2 * m] & 1, a1 = g[2 * m + 1] & 1;
+        h[m] = (uint8_t)(effects[m * T] > 0.0f ? (a0 | a1) : (a0 & a1));
+      }
+    } else {
+      for (int64_t b = 0; b < n_blocks; ++b) {
+        double s[2] = {0.0, 0.0};
+        for (int64_t m = block_start[b]; m < block_start[b + 1]; ++m) {
+          double w = 0.0;
+          for (int64_t t = 0; t < T; ++t) w += (double)effects[m * T + t];
+          s[0] += (g[2 * m] & 1) ? w : 0.0;
+          s[1] += (g[2 * m + 1] & 1) ? w : 0.0;
+        }
+        const int best = s[1] > s[0] ? 1 : 0;
+        for (int64_t m = block_start[b]; m < block_start[b + 1]; ++m) h[m] = g[2 * m + best] & 1;
+      }
+    }
+    if (ohp) memcpy(ohp + i * M, h, (size_t)M);
+    if (ohv)
+      for (int64_t t = 0; t < T; ++t) {
+        double acc = 0.0;
+        for (int64_t m = 0; m < M; ++m) acc += h[m] ? (double)effects[m * T + t] : 0.0;
+        ohv[i * T + t] = (float)(2.0 * acc);
+      }
+  }
+  free(h);
+}
+
 void bo_selection_actions(const float *scores, int64_t E, int64_t n, int64_t k,
                           int64_t n_crosses, uint32_t env_key[2], int32_t *out) {
   int64_t P = k * (k - 1) / 2, n_off = (n + n_crosses - 1) / n_crosses;

@@ -108,6 +108,16 @@ void bo_topk(const float *scores, int64_t n, int64_t k, int32_t *out);
 void bo_selection_actions(const float *scores, int64_t E, int64_t n, int64_t k,
                           int64_t n_crosses, uint32_t env_key[2], int32_t *out);
 
+/* Optimal haploid of every individual (utils/index_functions.py:36-78) and its value (:21-33).
+ *   pop (n, M, 2) u8; effects (M, T) f32; block_start (n_blocks + 1) marker offsets, or
+ *   n_blocks = 0 for the blockless rule: OHP[m] = any(alleles) where effects[m, 0] > 0, else
+ *   all(alleles) (:66-78; `positive_mask` is chromax's, [EXTERNAL/UNVERIFIED]: effect > 0).
+ *   With blocks (:44-63): per block the haplotype d with the larger sum_m sum_t pop[i,m,d] *
+ *   effects[m,t] (first on ties, like argmax) supplies the block.
+ *   ohp (n, M) u8 or NULL; ohv (n, T) f32 or NULL = 2 * sum_m OHP[i,m] * effects[m,t], f64 sums. */
+void bo_optimal_haploid(const uint8_t *pop, int64_t n, int64_t M, const float *effects, int64_t T,
+                        const int32_t *block_start, int64_t n_blocks, uint8_t *ohp, float *ohv);
+
 /* number of OpenMP threads the batch functions will use */
 int bo_num_threads(void);
 void bo_set_num_threads(int n);

@@ -186,6 +186,21 @@ def selection_actions(scores, k: int, n_crosses: int, env_key):
     return out, key
 
 
+def optimal_haploid(pop, effects, block_start=None):
+    """-> (OHP (n, M) u8, OHV (n, T) f32); block_start: marker offsets of the blocks, or None."""
+    g = np.ascontiguousarray(pop, np.uint8)
+    eff = np.ascontiguousarray(effects, np.float32)
+    eff = eff if eff.ndim == 2 else eff[:, None]
+    n, M, _ = g.shape
+    T = eff.shape[1]
+    bs = None if block_start is None else np.ascontiguousarray(block_start, np.int32)
+    ohp, ohv = np.empty((n, M), np.uint8), np.empty((n, T), np.float32)
+    lib().bo_optimal_haploid(_p(g, _u8p), c_i64(n), c_i64(M), _p(eff, _f32p), c_i64(T),
+                             None if bs is None else _p(bs, _i32p), c_i64(0 if bs is None else len(bs) - 1),
+                             _p(ohp, _u8p), _p(ohv, _f32p))
+    return ohp, ohv
+
+
 def num_threads() -> int:
     return lib().bo_num_threads()
 

@@ -201,3 +201,70 @@ def _tf_multi(keys, c0, c1):
         x0 = x0 + ks[(blk + 1) % 3]
         x1 = x1 + ks[(blk + 2) % 3] + _U32(blk + 1)
     return x0, x1
+
+
+# ---- selection indices (reference breedgym/utils/index_functions.py) ---------------------------
+def block_starts(B, chr_lens):
+    """Marker offsets of the B blocks of every chromosome, ceil(len / B) markers each, the last ones
+    cut at the chromosome end (index_functions.py:47-61).  Trailing blocks may be empty."""
+    out, start = [0], 0
+    for L in chr_lens:
+        step, end = -(-int(L) // B), start + int(L)
+        for _ in range(B):
+            start = min(start + step, end)
+            out.append(start)
+    return np.asarray(out, np.int32)
+
+
+def optimal_haploid_pop(pop, effects, block_start=None):
+    """(n, M, 2) -> (n, M) bool (index_functions.py:36-78)."""
+    pop = np.asarray(pop).astype(bool)
+    eff = np.asarray(effects, np.float64).reshape(len(effects), -1)
+    if block_start is None:
+        pos = np.asarray(effects, np.float32).reshape(len(effects), -1)[:, 0] > 0
+        return np.where(pos[None, :], pop.any(-1), pop.all(-1))
+    ohp = np.empty(pop.shape[:2], bool)
+    for s, e in zip(block_start[:-1], block_start[1:]):
+        val = np.einsum("nmd,m->nd", pop[:, s:e].astype(np.float64), eff[s:e].sum(1))
+        best = np.argmax(val, axis=-1)
+        ohp[:, s:e] = np.take_along_axis(pop[:, s:e], best[:, None, None], axis=2)[..., 0]
+    return ohp
+
+
+def optimal_haploid_value(pop, effects, F=0.0, block_start=None):
+    """index_functions.py:21-33: 2 * GEBV of the optimal haploid; the int(n * F) lowest-yield
+    individuals (stable argsort of the first trait's GEBV) get -inf."""
+    eff = np.asarray(effects, np.float64).reshape(len(effects), -1)
+    ohv = 2.0 * (optimal_haploid_pop(pop, effects, block_start).astype(np.float64) @ eff)
+    ohv = ohv.astype(np.float32).squeeze()
+    if F > 0:
+        ohv = np.array(ohv)
+        ohv[poor_yield_indices(pop, effects, F)] = -np.inf
+    return ohv
+
+
+def poor_yield_indices(pop, effects, F):
+    g = gebv(np.asarray(pop).astype(np.uint8), np.asarray(effects, np.float32).reshape(len(effects), -1))[:, 0]
+    return np.argsort(g, kind="stable")[: int(len(pop) * F)]
+
+
+def optimal_population_value(pop, effects, n, F=0.0, block_start=None):
+    """index_functions.py:81-109: greedy choice of n individuals whose optimal haploids stack best.
+    Returns the bool mask of the chosen individuals (the reference's "not OPV but a mask")."""
+    pop = np.asarray(pop).astype(bool)
+    eff = np.asarray(effects, np.float64).reshape(len(effects), -1)
+    T = eff.shape[1]
+    indices = np.delete(np.arange(len(pop)), poor_yield_indices(pop, effects, F))
+    output = np.zeros(len(pop), bool)
+    current = ~(np.asarray(effects, np.float32).reshape(len(effects), -1)[:, 0] > 0)
+    G = optimal_haploid_pop(pop[indices], effects, block_start)
+    for _ in range(n):
+        dummy = np.stack((G, np.broadcast_to(current[None, :], G.shape)), axis=2)
+        G = optimal_haploid_pop(dummy, effects, block_start)
+        best = int(np.argmax((G.astype(np.float64) @ eff).astype(np.float32))) // T
+        output[indices[best]] = True
+        current = G[best]
+        indices = np.delete(indices, best)
+        G = optimal_haploid_pop(pop[indices], effects, block_start)
+    assert np.count_nonzero(output) == n
+    return output

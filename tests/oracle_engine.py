@@ -115,6 +115,11 @@ class OracleEngine(EngineBase):
             return out
         return g
 
+    def optimal_haploid(self, pop, block_start=None, want_pop=True, want_value=True):
+        bs = None if block_start is None else block_start.numpy()
+        ohp, ohv = co.optimal_haploid(self._g(pop), self.effects, bs)
+        return (torch.from_numpy(ohp) if want_pop else None), (torch.from_numpy(ohv) if want_value else None)
+
     def reward_max(self, gebv, n_envs, out=None):
         self.calls["reward_max"] += 1
         r = torch.from_numpy(co.reward_max(gebv.numpy().reshape(n_envs, -1)))

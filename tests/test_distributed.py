@@ -62,7 +62,7 @@ def _env_sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _pop_sharded_worker(rank, world, port, q):
+def _pop_sharded_worker(rank, world, port, q, storage="bytes"):
     _setup(rank, world, port)
     from oracle_engine import OracleEngine
 
@@ -76,7 +76,7 @@ def _pop_sharded_worker(rank, world, port, q):
     n_local = N // world
     sim = Simulator(genetic_map=gm, engine=OracleEngine(gm.recombination_vec, gm.marker_effects), seed=0)
     rows = sim.engine.upload_population(geno[rank * n_local : (rank + 1) * n_local])
-    sp = ShardedPopulation(sim, rows)
+    sp = ShardedPopulation(sim, rows, storage=storage)
     scores_all = co.gebv(geno, gm.marker_effects)[:, 0]
     scores_all[7] = scores_all[31] = scores_all[3]  # ties across shards resolve to the lower global index
     for k in (1, 5, 13, n_local, n_local + 4):
@@ -99,11 +99,11 @@ def _pop_sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _run(worker, world=2):
+def _run(worker, world=2, extra=()):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, *extra)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -123,6 +123,7 @@ def test_env_sharded_two_ranks():
 
 
 @pytest.mark.timeout(180)
-def test_population_sharded_two_ranks():
-    out = _run(_pop_sharded_worker)
+@pytest.mark.parametrize("storage", ["bytes", "bits"])
+def test_population_sharded_two_ranks(storage):
+    out = _run(_pop_sharded_worker, extra=(storage,))
     assert out[0][1] == out[1][1]  # identical global top-k on every rank

@@ -499,7 +499,8 @@ def test_empty_and_degenerate_calls(rng):
     assert np.array_equal(got, ref) and g[0, 0, 0] == 2.0 * ref.sum()
 
 
-def test_population_sharded_flow_single_rank(rng):
+@pytest.mark.parametrize("storage", ["bytes", "bits"])
+def test_population_sharded_flow_single_rank(storage, rng):
     """ShardedPopulation with world_size 1 on the device: global top-k, replicated winners, one
     generation -- the collectives degenerate to identities, the kernels are the real ones"""
     from breedgym_amd import Simulator
@@ -510,7 +511,7 @@ def test_population_sharded_flow_single_rank(rng):
     gm = synthetic_genetic_map(M, n_chr=3)
     geno = synthetic_genotypes(N, M).view(np.uint8)
     sim = Simulator(genetic_map=gm, seed=0)
-    sp = ShardedPopulation(sim, sim.engine.upload_population(geno))
+    sp = ShardedPopulation(sim, sim.engine.upload_population(geno), storage=storage)
     best = sp.global_topk(sp.gebv()[:, 0], k)
     assert np.array_equal(best.cpu().numpy(), co.topk(co.gebv(geno, gm.marker_effects)[:, 0], k))
     parents = sp.gather_rows(best)
@@ -521,3 +522,44 @@ def test_population_sharded_flow_single_rank(rng):
     ref, refkey = co.cross(geno[best.cpu().numpy()][None], pairs.numpy()[None], gm.recombination_vec, co.key_from_seed(5), 1)
     assert np.array_equal(sim.engine.download_population(sp.rows).view(np.uint8), ref[0]) and np.array_equal(key, refkey)
     assert gebv_close(np.asarray(g), co.gebv(ref[0], gm.marker_effects, want64=True)[1], gm.marker_effects)
+
+
+@pytest.mark.parametrize("T", [1, 2, 9])
+@pytest.mark.parametrize("B", [None, 1, 4])
+def test_optimal_haploid_kernel(T, B, rng):
+    """bh_optimal_haploid against the C restatement of utils/index_functions.py:21-78."""
+    from oracle import numpy_oracle as no
+
+    M, N = 1237, 41
+    pop = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eff[5] = 0.0  # a zero effect is not positive
+    eng = make_engine(np.full(M, 0.01, np.float32), eff)
+    bs = None if B is None else no.block_starts(B, [400, 3, 834])  # one chromosome shorter than B blocks
+    dbs = None if bs is None else torch.from_numpy(bs).to(eng.device)
+    ohp, ohv = eng.optimal_haploid(eng.upload_population(pop), dbs)
+    ref_p, ref_v = co.optimal_haploid(pop, eff, bs)
+    assert np.array_equal(ohp.cpu().numpy(), ref_p)
+    assert np.allclose(ohv.cpu().numpy(), ref_v, rtol=1e-6, atol=1e-4)
+    only_v = eng.optimal_haploid(eng.upload_population(pop), dbs, want_pop=False)[1]
+    assert torch.equal(only_v, ohv)
+
+
+def test_index_functions_on_device(rng):
+    """OHV with the poor-yield mask and the greedy OPV mask end to end on the GPU == NumPy restatement."""
+    from breedgym_amd import Simulator
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.utils import index_functions as ix
+    from oracle import numpy_oracle as no
+
+    M, N = 900, 60
+    gm = synthetic_genetic_map(M, n_chr=5, n_traits=1, seed=2)
+    geno = synthetic_genotypes(N, M, seed=3)
+    sim = Simulator(genetic_map=gm, seed=0)
+    pop = sim.device_put(geno)
+    for B in (None, 2):
+        bs = None if B is None else no.block_starts(B, gm.chr_lens)
+        ohv = ix.optimal_haploid_value(sim.GEBV_model, F=0.2, B=B, chr_lens=gm.chr_lens)(pop)
+        assert np.allclose(ohv, no.optimal_haploid_value(geno, gm.marker_effects, 0.2, bs), rtol=1e-6)
+        mask = ix.optimal_population_value(sim.GEBV_model, 7, F=0.2, B=B, chr_lens=gm.chr_lens)(pop)
+        assert np.array_equal(mask, no.optimal_population_value(geno, gm.marker_effects, 7, 0.2, bs))

@@ -422,3 +422,41 @@ def test_vec_bit_plane_storage_is_invisible(data, observations, env_rng):
         make_vec(data, observations="lazy")
     with pytest.raises(ValueError):
         make_vec(data, storage="nibbles")
+
+
+@pytest.mark.parametrize("B", [None, 1, 3])
+def test_index_functions(data, B):
+    """utils/index_functions.py of the reference: OHP / OHV / OPV against the NumPy restatement, and
+    the C restatement against the NumPy one."""
+    from breedgym_amd.utils import index_functions as ix
+    from oracle import numpy_oracle as no
+
+    gm, geno = data
+    eff1 = gm.marker_effects[:, :1]
+    gm1 = synthetic_genetic_map(M, n_chr=3, n_traits=1, seed=5)
+    sim = Simulator(genetic_map=gm1, engine=OracleEngine(gm1.recombination_vec, gm1.marker_effects), seed=0)
+    eff1 = gm1.marker_effects
+    pop = sim.device_put(geno)
+    chr_lens = gm1.chr_lens
+    bs = None if B is None else no.block_starts(B, chr_lens)
+    if B is not None:
+        assert np.array_equal(ix.block_offsets(B, chr_lens), bs) and bs[-1] == M
+    # C restatement == NumPy restatement
+    ohp_c, ohv_c = co.optimal_haploid(geno.view(np.uint8), eff1, bs)
+    assert np.array_equal(ohp_c.astype(bool), no.optimal_haploid_pop(geno, eff1, bs))
+    assert np.allclose(ohv_c.squeeze(), no.optimal_haploid_value(geno, eff1, 0, bs), rtol=1e-6)
+    # the product's module through the engine seam
+    got = ix.optimal_haploid_pop(sim.GEBV_model, pop, B, chr_lens)
+    assert got.shape == (N, M) and got.dtype == torch.bool
+    assert np.array_equal(np.asarray(got), no.optimal_haploid_pop(geno, eff1, bs))
+    for F in (0, 0.25):
+        ohv = ix.optimal_haploid_value(sim.GEBV_model, F=F, B=B, chr_lens=chr_lens)(pop)
+        ref = no.optimal_haploid_value(geno, eff1, F, bs)
+        assert ohv.shape == (N,) and np.allclose(ohv, ref, rtol=1e-6) and np.isinf(ohv).sum() == int(N * F)
+        mask = ix.optimal_population_value(sim.GEBV_model, 5, F=F, B=B, chr_lens=chr_lens)(pop)
+        assert mask.dtype == bool and mask.sum() == 5
+        assert np.array_equal(mask, no.optimal_population_value(geno, eff1, 5, F, bs))
+    assert np.allclose(np.asarray(ix.yield_index(sim.GEBV_model)(pop)), co.gebv(geno.view(np.uint8), eff1)[:, 0])
+    if B is not None:
+        with pytest.raises(AssertionError):
+            ix.optimal_haploid_pop(sim.GEBV_model, pop, B, None)

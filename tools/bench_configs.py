@@ -75,9 +75,11 @@ gm4 = synthetic_genetic_map(100_000, n_chr=21)
 sim = Simulator(genetic_map=gm4, seed=0)
 g8 = synthetic_genotypes(2048, 100_000)
 rows8 = sim.engine.upload_population(np.concatenate([g8] * 4))
-sp = ShardedPopulation(sim, rows8)
 pairs = torch.from_numpy(np.random.default_rng(0).integers(0, 6553, (8192, 2), dtype=np.int32)).cuda()
 key = np.array([0, 5], np.uint32)
-dt = timed(lambda: sp.select_and_cross(6553, pairs, key), 5, warm=2)
-print(f"configs[3] one rank: GEBV + top-6,553 of 8,192 + gather winners + 8,192 crosses x 100k: {dt*1e3:.2f} ms/generation, "
-      f"{8192/dt/1e6:.2f} M crosses/s per GPU")
+for storage in ("bytes", "bits"):
+    sp = ShardedPopulation(sim, rows8, storage=storage)
+    dt = timed(lambda: sp.select_and_cross(6553, pairs, key), 5, warm=2)
+    print(f"configs[3] one rank, storage={storage}: GEBV + top-6,553 of 8,192 + gather winners + 8,192 crosses x 100k: "
+          f"{dt*1e3:.2f} ms/generation, {8192/dt/1e6:.2f} M crosses/s per GPU")
+    del sp
