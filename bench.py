@@ -152,10 +152,10 @@ def main():
     gm = synthetic_genetic_map(N_MARKERS, n_chr=10, n_traits=1, seed=1)
     geno = synthetic_genotypes(N_GERMPLASM, N_MARKERS, seed=0)
 
-    def make_env(env_rng):
+    def make_env(env_rng, **kw):
         return VecBreedGym(
             num_envs=N_ENVS, initial_population=geno, individual_per_gen=N_PER_ENV, num_generations=N_GENERATIONS,
-            autoreset=True, reward_shaping=True, env_rng=env_rng, sync_rewards=False, genetic_map=gm,
+            autoreset=True, reward_shaping=True, env_rng=env_rng, sync_rewards=False, genetic_map=gm, **kw,
         )
 
     # Headline: the drop-in configuration.  env_rng="shared" is what the reference computes -- its
@@ -192,6 +192,18 @@ def main():
     if use_dist:
         dist.all_reduce(ti, op=dist.ReduceOp.MAX)
     kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
+
+    # Populations kept as bit planes between steps: same observations when they are
+    # written eagerly, a handle that expands on demand when they are not.  One GPU only: extra lines,
+    # not the headline.
+    bits = {}
+    if world == 1:
+        for obs in ("eager", "lazy"):
+            env_b = make_env("shared", storage="bits", observations=obs)
+            env_b.reset(seed=100 + rank)
+            dt_b = time_steps(env_b, actions, args.steps, args.warmup, barrier)
+            bits[obs] = {"value": args.steps * N_ENVS * N_PER_ENV / dt_b, "ms_per_step": dt_b / args.steps * 1e3}
+            del env_b
 
     # algorithmic bytes per launch: 2 parents x 2M read + 2M written per cross
     alg_bytes = 6 * N_MARKERS * crosses_per_step
@@ -240,6 +252,12 @@ def main():
                 "achieved_GBps": alg_bytes / (kern_ms_i * 1e-3) / 1e9,
             },
         }
+        if bits:
+            line["bit_plane_storage"] = {
+                "note": "storage='bits': populations live as 1 bit per allele between steps; 'eager' also writes the "
+                        "byte-layout observation in the same launch, 'lazy' hands out a handle that expands on demand",
+                **bits,
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(gm, geno, 0)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

@@ -377,9 +377,14 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
   // behind Threefry, or the memory pipes drain.
   __builtin_amdgcn_s_setprio(3);
 
-  // NC independent chains per sum: one chain of dependent f64 FMAs waits out the FMA latency eight
-  // times per vector when few waves share the SIMD
-  constexpr int NC = NT * R <= 4 ? 4 : (NT * R <= 8 ? 2 : 1);
+  // NC independent chains per sum.  Long rows (HBM-resident sets, few waves per SIMD doing the sums)
+  // gain 8 % from four chains -- a single chain of dependent f64 FMAs waits out the FMA latency
+  // eight times per vector; 10k-marker rows lose 2 % to the extra registers (tools/run_ab_chains.sh).
+#if defined(BH_GEBV_CHAINS)  // tuning experiments only
+  constexpr int NC = BH_GEBV_CHAINS;
+#else
+  constexpr int NC = !LONG ? 1 : (NT * R <= 4 ? 4 : (NT * R <= 8 ? 2 : 1));
+#endif
   double acc[R][NT][NC];
 #pragma unroll
   for (int r = 0; r < R; ++r)
