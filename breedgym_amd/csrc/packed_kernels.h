@@ -57,21 +57,13 @@ __device__ __forceinline__ uint32_t gamete8(uint32_t p16, uint32_t z8) {
 }
 
 // One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
-// them, as in row_role); MODE_CROSS or MODE_GATHER.
-//
-// A row is only ceil(M / 512) trips of 64 lanes, and a trip that waits for its own loads costs a full
-// memory latency (measured: 18 us for 4096 x 10k-marker rows whatever the traffic).  So the loads run
-// ahead of the arithmetic: the 2-byte words of the next CH trips and the marker effects of the next
-// trip are requested before the current trip is expanded, stored and summed.  (The compiler cannot
-// do this itself: the byte stores may alias anything.)
+// them, as in row_role); MODE_CROSS or MODE_GATHER.  The loop is deliberately plain: requesting the
+// next trips' words ahead of the current trip's stores (software pipelining) was measured -- it costs
+// registers the mask role next door needs more than the row role needs the overlap.
 template <int TT, int MODE, int R>
 __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int block, const int wave) {
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   constexpr int NT = TT > 0 ? TT : 1;
-  constexpr int CH = R == 1 ? 4 : 2;           // trips whose genotype words are in flight together
-  constexpr bool EPF = TT == 1 || TT == 2;     // effects one trip ahead (16 VGPRs per trait)
-  constexpr int NE = EPF ? TT : 1;
-  constexpr int NC = TT * R <= 4 ? 4 : (TT * R <= 8 ? 2 : 1);  // accumulation chains per (row, trait)
   const int lane = threadIdx.x & 63;
   const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
   if (c0 >= p.n_rows) return;
@@ -101,114 +93,57 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
   }
   __builtin_amdgcn_s_setprio(3);
 
-  double acc[R][NT][NC];
+  double acc[R][NT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int k = 0; k < NC; ++k) acc[r][t][k] = 0.0;
+    for (int t = 0; t < NT; ++t) acc[r][t] = 0.0;
 
-  const int ntrips = (p.nvp + 63) >> 6;
-  struct Words {
-    uint32_t a[R][CH], b[R][CH], z[R][CH];
-  };
-  // words of trips t0 .. t0+CH-1 for this lane; lanes past the end of the row re-read a word that exists
-  auto load_words = [&](int t0, Words &w) {
+  for (int v = lane; v < p.nvp; v += 64) {
+    uint32_t a[R], b[R], z[R];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      int v = (t0 + j) * 64 + lane;
-      v = v < p.nvp ? v : lane & 7;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        w.a[r][j] = src0[r][v];
-        if constexpr (MODE == MODE_CROSS) {
-          w.b[r][j] = src1[r][v];
-          w.z[r][j] = Z16[r][v];
-        } else {
-          w.b[r][j] = 0;
-          w.z[r][j] = 0;
-        }
+    for (int r = 0; r < R; ++r) {
+      a[r] = src0[r][v];
+      if constexpr (MODE == MODE_CROSS) {
+        b[r] = src1[r][v];
+        z[r] = Z16[r][v];
       }
     }
-  };
-  struct Eff8 {
-    double2 e[4];
-  };
-  auto load_eff = [&](int t, int trait) {
-    int v = t * 64 + lane;
-    v = v < p.nvec ? v : p.nvec - 1;
-    const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)trait * p.effPitch + 8 * (int64_t)v);
-    Eff8 r;
-    r.e[0] = ep[0];
-    r.e[1] = ep[1];
-    r.e[2] = ep[2];
-    r.e[3] = ep[3];
-    return r;
-  };
-  // NC independent chains per sum: a single chain of dependent f64 FMAs waits out the FMA latency
-  // eight times per trip when few waves share the SIMD
-  auto accumulate = [&](const Dosage8 &d, const Eff8 &f, double (&s)[NC]) {
-    const double e[8] = {f.e[0].x, f.e[0].y, f.e[1].x, f.e[1].y, f.e[2].x, f.e[2].y, f.e[3].x, f.e[3].y};
+    const bool inrow = v < p.nvec;  // the packed row is padded to whole 64-marker words
+    uint4 oo[R];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s[k % NC] = fma(d.d[k], e[k], s[k % NC]);
-  };
-
-  Words cur;
-  load_words(0, cur);
-  Eff8 enext[NE];
-  if constexpr (EPF) {
+    for (int r = 0; r < R; ++r) {
+      uint32_t o = a[r];
+      if constexpr (MODE == MODE_CROSS) o = gamete8(a[r], z[r] & 0xffu) | (gamete8(b[r], z[r] >> 8) << 8);
+      if (dstp[r]) dstp[r][v] = (uint16_t)o;
+      oo[r] = expand_vector(o);
+      if (dstb[r] && inrow) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)v) = oo[r];
+    }
+    if constexpr (TT > 0) {
+      if (inrow) {
 #pragma unroll
-    for (int t = 0; t < TT; ++t)
-      if (t < p.tcount) enext[t] = load_eff(0, t);
-  }
-
-  for (int t0 = 0; t0 < ntrips; t0 += CH) {
-    Words nxt;
-    if (t0 + CH < ntrips) load_words(t0 + CH, nxt);
+        for (int t = 0; t < TT; ++t) {
+          if (t < p.tcount) {
+            const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)t * p.effPitch + 8 * (int64_t)v);
+            const double2 e0 = ep[0], e1 = ep[1], e2 = ep[2], e3 = ep[3];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int t = t0 + j;
-      if (t < ntrips) {
-        const int v = t * 64 + lane;
-        const bool inp = v < p.nvp, inrow = v < p.nvec;
-        Eff8 ecur[NE];
-        if constexpr (EPF) {
-#pragma unroll
-          for (int q = 0; q < TT; ++q)
-            if (q < p.tcount) {
-              ecur[q] = enext[q];
-              if (t + 1 < ntrips) enext[q] = load_eff(t + 1, q);
+            for (int r = 0; r < R; ++r) {
+              const Dosage8 d = dosages(oo[r]);
+              double s = acc[r][t];
+              s = fma(d.d[0], e0.x, s);
+              s = fma(d.d[1], e0.y, s);
+              s = fma(d.d[2], e1.x, s);
+              s = fma(d.d[3], e1.y, s);
+              s = fma(d.d[4], e2.x, s);
+              s = fma(d.d[5], e2.y, s);
+              s = fma(d.d[6], e3.x, s);
+              s = fma(d.d[7], e3.y, s);
+              acc[r][t] = s;
             }
-        }
-        uint4 oo[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          uint32_t o = cur.a[r][j];
-          if constexpr (MODE == MODE_CROSS)
-            o = gamete8(cur.a[r][j], cur.z[r][j] & 0xffu) | (gamete8(cur.b[r][j], cur.z[r][j] >> 8) << 8);
-          if (dstp[r] && inp) dstp[r][v] = (uint16_t)o;
-          oo[r] = expand_vector(o);
-          if (dstb[r] && inrow) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)v) = oo[r];
-        }
-        if constexpr (TT > 0) {
-          if (inrow) {
-#pragma unroll
-            for (int q = 0; q < TT; ++q)
-              if (q < p.tcount) {
-                Eff8 f;
-                if constexpr (EPF)
-                  f = ecur[q];
-                else
-                  f = load_eff(t, q);
-#pragma unroll
-                for (int r = 0; r < R; ++r) accumulate(dosages(oo[r]), f, acc[r][q]);
-              }
           }
         }
       }
     }
-    cur = nxt;
   }
 
   if constexpr (TT > 0) {
@@ -216,12 +151,10 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        double s = acc[r][t][0];
-#pragma unroll
-        for (int k = 1; k < NC; ++k) s += acc[r][t][k];
+        double s = acc[r][t];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        acc[r][t][0] = s;
+        acc[r][t] = s;
       }
     if (lane == 0) {
 #pragma unroll
@@ -229,7 +162,7 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
         if (live[r]) {
 #pragma unroll
           for (int t = 0; t < TT; ++t)
-            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t][0];
+            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
         }
     }
   }
