@@ -460,3 +460,28 @@ def test_index_functions(data, B):
     if B is not None:
         with pytest.raises(AssertionError):
             ix.optimal_haploid_pop(sim.GEBV_model, pop, B, None)
+
+
+def test_index_functions_drive_the_simplified_env(data):
+    """scripts/compare_indexes.py of the reference: OHV / OPV as the selection index of
+    SimplifiedBreedGym, through reset(options={"index": ...})."""
+    from breedgym_amd.utils import index_functions as ix
+    from breedgym_amd.wrappers import SimplifiedBreedGym
+
+    _, geno = data
+    gm1 = synthetic_genetic_map(M, n_chr=3, n_traits=1, seed=5)
+    base = BreedGym(initial_population=geno, genetic_map=gm1,
+                    engine=OracleEngine(gm1.recombination_vec, gm1.marker_effects))
+    env = SimplifiedBreedGym(base, individual_per_gen=24)
+    model, chr_lens = env.unwrapped.simulator.GEBV_model, env.unwrapped.simulator.chr_lens
+    for index in (ix.yield_index(model), ix.optimal_haploid_value(model, F=0.3, B=2, chr_lens=chr_lens),
+                  ix.optimal_population_value(model, 6, F=0.2, B=2, chr_lens=chr_lens)):
+        obs, _ = env.reset(seed=3, options={"index": index})
+        for _ in range(3):
+            before = np.asarray(env.unwrapped.population).copy()
+            scores = np.asarray(index(env.unwrapped.population), np.float32)
+            obs, r, _, _, _ = env.step({"n_bests": 6, "n_crosses": 8})
+            assert len(obs["GEBV"]) == 24 and np.isfinite(r)
+            # the elite that was crossed is the index's own top 6 (ties to the lower position)
+            elite = np.argsort(-scores, kind="stable")[:6]
+            assert np.array_equal(np.asarray(env.unwrapped.simulator.select(before, 6, index)[1]), elite)
