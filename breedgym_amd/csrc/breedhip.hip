@@ -98,7 +98,10 @@ int row_waves_for(const bh_ctx *c, int64_t n_rows) { return (c->M > 16384 && n_r
 size_t mask_group_lds(const bh_ctx *c) { return (size_t)(c->nwh + 1) * 32; }  // S[nwh + 1][4] u64
 
 // rows one wave streams at once (the effect vectors are loaded once per trip for all of them)
-constexpr int kRowsPerWaveCross = 2, kRowsPerWavePlain = 4;
+#ifndef BH_ROWS_PER_WAVE_CROSS  // tuning experiments only
+#define BH_ROWS_PER_WAVE_CROSS 2
+#endif
+constexpr int kRowsPerWaveCross = BH_ROWS_PER_WAVE_CROSS, kRowsPerWavePlain = 4;
 
 template <int WAVES, int TT, int MODE, int R>
 int launch_row(const bh_ctx *c, bh::RowParams p) {
