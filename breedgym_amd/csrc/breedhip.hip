@@ -191,11 +191,28 @@ int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bo
 
 // one launch: waves 0-3 of every workgroup stream `rp` (generation g, R rows per wave), waves 4-7
 // fill `mp` (generation g+1) with MW waves per cross.  Only for rows one wave handles.
+// Grid of the two-role launch.  With somewhat more mask units than row workgroups (shared keys at
+// 2k x 100k: 2048 against 1024) a grid as long as the mask work leaves a tail of mask-only workgroups
+// behind the streaming (+220 us measured); the workgroups of a grid as long as the row work take the
+// mask units in turns instead (cross_kernel).  With many more mask units than row workgroups the
+// launch is mask-bound whatever is done, and short workgroups balance better over the CUs than
+// long-lived ones (2.49 ms against 2.10 ms at 8192 independent 100k-marker crosses): no turns then.
+// Only for four mask waves per cross: in the one-wave-per-cross kernels the loop costs the registers
+// that keep eight waves per SIMD resident.
+#ifndef BH_MASK_TURNS_MAX  // tuning experiments only (1 = never take turns)
+#define BH_MASK_TURNS_MAX 4
+#endif
+constexpr int kMaskTurnsMax = BH_MASK_TURNS_MAX;
+inline int two_role_grid(int row_blocks, int mask_blocks) {
+  if (mask_blocks <= row_blocks) return row_blocks;
+  return mask_blocks <= kMaskTurnsMax * row_blocks ? row_blocks : mask_blocks;
+}
+
 template <int TT, int MW, int R>
 int launch_cross_tt(bh_ctx *c, bh::RowParams rp, const bh::MaskParams &mp) {
   rp.n_blocks = (rp.n_rows + 4 * R - 1) / (4 * R);
   const size_t lds = (size_t)mp.group_lds * (4 / MW);
-  const int grid = rp.n_blocks > mp.n_blocks ? rp.n_blocks : mp.n_blocks;
+  const int grid = MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks);
   if (R == 2 && c->M > 16384)
     hipLaunchKernelGGL((bh::cross_kernel<TT, MW, R, R == 2>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
   else
@@ -227,7 +244,7 @@ template <int TT, int MW, int R>
 int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   rp.n_blocks = (rp.n_rows + 4 * R - 1) / (4 * R);
   const size_t lds = (size_t)mp.group_lds * (4 / MW);
-  const int grid = rp.n_blocks > mp.n_blocks ? rp.n_blocks : mp.n_blocks;
+  const int grid = MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks);
   hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));

@@ -178,10 +178,13 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 template <int TT, int MW, int R>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
-  __shared__ unsigned counter;
+  __shared__ unsigned counter, done;
   const int wave = (int)(threadIdx.x >> 6);
   if constexpr (MW == 4) {
-    if (threadIdx.x == 0) counter = 0;
+    if (threadIdx.x == 0) {
+      counter = 0;
+      done = 0;
+    }
     __syncthreads();
   }
 #if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation_packed.sh)
@@ -191,11 +194,12 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 #endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) packed_row_role<TT, MODE_CROSS, R>(rp, (int)blockIdx.x, wave);
-  } else if ((int)blockIdx.x < mp.n_blocks) {
-    if constexpr (MW == 1)
-      mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
-    else
-      mask_role<4, SYNC_COUNTER>(mp, (int)blockIdx.x, wave - 4, lds_raw, &counter);
+  } else if constexpr (MW == 1) {
+    if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
+  } else {
+    int iter = 0;  // crosses in turns when the grid is shorter than the mask work (cross_kernel)
+    for (int mb = (int)blockIdx.x; mb < mp.n_blocks; mb += (int)gridDim.x, ++iter)
+      mask_role<4, SYNC_COUNTER>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
   }
 }
 

@@ -149,9 +149,13 @@ __device__ __forceinline__ KeySched key_sched(uint32_t k0, uint32_t k1) {
 //   SYNC_COUNTER four mask waves next to four row waves that must not be held up: every mask
 //                wave bumps an LDS counter when its site words are written, wave 0 waits for it.
 //                `counter` was zeroed before a workgroup barrier at kernel entry.
+// SYNC_COUNTER groups may be called for several crosses in turn (`iter` = 0, 1, ..: the workgroup's
+// share of the mask work, see cross_kernel): `counter` then counts arrivals over all turns, and
+// `done` (the number of finished prefix passes) keeps the other waves from overwriting site words
+// wave 0 is still reading.
 template <int WAVES, int SYNC>
 __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, const int wave, uint8_t *lds_raw,
-                                          unsigned *counter) {
+                                          unsigned *counter, const int iter = 0, unsigned *done = nullptr) {
   static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or four");
   static_assert((WAVES == 1) == (SYNC == SYNC_WAVE), "one wave needs no hand-off, four need one");
   constexpr int GROUPS = 4 / WAVES;
@@ -178,6 +182,14 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     rk11 = __builtin_amdgcn_readlane(rw, 3);
   }
   const KeySched ka = key_sched(rk00, rk01), kb = key_sched(rk10, rk11);
+  if constexpr (SYNC == SYNC_COUNTER) {
+    if (iter > 0) {  // the previous cross's prefix pass must be through with the site words
+      for (int spin = 0; spin < (1 << 24); ++spin) {
+        if (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)iter) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
 
   // ---- phase A: recombination sites.  Everything around the Threefry block is kept off the
   // vector ALU where possible: thresholds come through a buffer descriptor (lane offset in a
@@ -257,7 +269,8 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (wv != 0) return;
     for (int spin = 0; spin < (1 << 24); ++spin) {
-      if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)WAVES) break;
+      if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)(WAVES * (iter + 1)))
+        break;
       __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -290,6 +303,9 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
         z.w = __builtin_amdgcn_perm(b1, a1, 0x07030602u);
         *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
       }
+    }
+    if constexpr (SYNC == SYNC_COUNTER) {
+      if (lane == 0) __hip_atomic_store(done, (unsigned)(iter + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }
@@ -516,10 +532,13 @@ __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
 template <int TT, int MW, int R, bool LONG>
 __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
-  __shared__ unsigned counter;
+  __shared__ unsigned counter, done;
   const int wave = (int)(threadIdx.x >> 6);
   if constexpr (MW == 4) {
-    if (threadIdx.x == 0) counter = 0;
+    if (threadIdx.x == 0) {
+      counter = 0;
+      done = 0;
+    }
     __syncthreads();
   }
 #if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation.sh)
@@ -529,11 +548,15 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
 #endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) row_role<1, TT, MODE_CROSS, R, LONG>(rp, (int)blockIdx.x, wave, nullptr);
-  } else if ((int)blockIdx.x < mp.n_blocks) {
-    if constexpr (MW == 1)
-      mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
-    else
-      mask_role<4, SYNC_COUNTER>(mp, (int)blockIdx.x, wave - 4, lds_raw, &counter);
+  } else if constexpr (MW == 1) {
+    if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
+  } else {
+    // the grid may be shorter than the mask work (somewhat more keyed crosses than row workgroups):
+    // every workgroup then takes several crosses in turn, so that no tail of mask-only workgroups
+    // is left when the streaming is over (two_role_grid in breedhip.hip)
+    int iter = 0;
+    for (int mb = (int)blockIdx.x; mb < mp.n_blocks; mb += (int)gridDim.x, ++iter)
+      mask_role<4, SYNC_COUNTER>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
   }
 }
 

@@ -563,3 +563,41 @@ def test_index_functions_on_device(rng):
         assert np.allclose(ohv, no.optimal_haploid_value(geno, gm.marker_effects, 0.2, bs), rtol=1e-6)
         mask = ix.optimal_population_value(sim.GEBV_model, 7, F=0.2, B=B, chr_lens=gm.chr_lens)(pop)
         assert np.array_equal(mask, no.optimal_population_value(geno, gm.marker_effects, 7, 0.2, bs))
+
+
+@pytest.mark.parametrize("M,E,n,mode", [(64, 5, 1000, 1), (16392, 1, 1100, 1), (16392, 2, 1050, 0)])
+def test_mask_units_taken_in_turns(M, E, n, mode, rng):
+    """More keyed crosses than the launch has workgroups: every workgroup's mask waves take several
+    crosses in turn (one wave per cross for short rows, four per cross with the LDS hand-off for long
+    ones).  Three generations, so that masks made by the run-ahead role are the ones consumed."""
+    NP = 6
+    r = (rng.random(M) * 0.01).astype(np.float32)
+    r[:: max(1, M // 6)] = 0.5
+    eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+    eng = make_engine(r, eff)
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    rows = eng.upload_population(pool.reshape(E * NP, M, 2))
+    key, refkey = co.key_from_seed(21).copy(), co.key_from_seed(21)
+    ref, n_pool = pool, NP
+    for gen in range(3):
+        idx = rng.integers(0, n_pool, (E, n, 2), dtype=np.int32)
+        out = eng.empty_population(E * n)
+        gebv = eng.empty((E, n, 1), torch.float32)
+        eng.cross(rows, E, n_pool, torch.from_numpy(idx).to(eng.device), n, key, mode, out, gebv)
+        ref, refkey = co.cross(ref, idx, r, refkey, mode)
+        got = eng.download_population(out).view(np.uint8).reshape(E, n, M, 2)
+        assert np.array_equal(got, ref), f"generation {gen}"
+        assert np.array_equal(key, refkey)
+        assert gebv_close(gebv.cpu().numpy(), co.gebv(ref, eff, want64=True)[1], eff)
+        rows, n_pool = out, n
+    # the same through the bit-plane kernels
+    prow = eng.pack(eng.upload_population(pool.reshape(E * NP, M, 2)))
+    key, refkey, ref, n_pool = co.key_from_seed(21).copy(), co.key_from_seed(21), pool, NP
+    for gen in range(2):
+        idx = rng.integers(0, n_pool, (E, n, 2), dtype=np.int32)
+        outp, outb = eng.empty_packed(E * n), eng.empty_population(E * n)
+        eng.cross_packed(prow, E, n_pool, torch.from_numpy(idx).to(eng.device), n, key, mode, outp, outb)
+        ref, refkey = co.cross(ref, idx, r, refkey, mode)
+        assert np.array_equal(eng.download_population(outb).view(np.uint8).reshape(E, n, M, 2), ref)
+        assert np.array_equal(key, refkey)
+        prow, n_pool = outp, n
