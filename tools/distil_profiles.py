@@ -16,8 +16,9 @@ dst.mkdir(exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(str(src / pattern))
-    return f[0] if f else None
+    # gpurun merges new files next to those of earlier calls: take the newest
+    f = sorted(glob.glob(str(src / pattern)), key=lambda x: Path(x).stat().st_mtime)
+    return f[-1] if f else None
 
 
 ks = one("kt/*/*kernel_stats.csv")
