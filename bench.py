@@ -98,23 +98,33 @@ def time_steps(env, actions, steps, warmup, barrier):
 
 
 def time_cross_launches(env, actions, reps):
-    """HIP events around `reps` back-to-back launches of the hot-path kernel alone (the fused
-    two-role cross_kernel: streams this generation, makes the next one's masks)."""
+    """HIP events around `reps` back-to-back launches of the hot-path kernel alone (the fused two-role
+    launch: streams this generation, makes the next one's masks), in the env's own storage layout."""
     import torch
 
     eng = env.simulator.engine
     E, n = env.num_envs, env._n
-    rows_in = env._rows
-    out = eng.empty_population(E * n)
     gebv = eng.empty((E, n, eng.n_traits), torch.float32)
     key = np.ascontiguousarray(env.simulator.random_key.copy())
+    if env.storage == "bits":
+        pool, outp = env._prows, eng.empty_packed(E * n)
+        obs = eng.empty_population(E * n) if env.observations == "eager" else None
+
+        def launch(i):
+            eng.cross_packed(pool, E, n, actions[i % len(actions)], n, key, env._rng_mode, outp, obs, gebv)
+    else:
+        pool, out = env._rows, eng.empty_population(E * n)
+
+        def launch(i):
+            eng.cross(pool, E, n, actions[i % len(actions)], n, key, env._rng_mode, out, gebv)
+
     for i in range(5):
-        eng.cross(rows_in, E, n, actions[i % len(actions)], n, key, env._rng_mode, out, gebv)
+        launch(i)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     ev0.record()
     for i in range(reps):
-        eng.cross(rows_in, E, n, actions[i % len(actions)], n, key, env._rng_mode, out, gebv)
+        launch(i)
     ev1.record()
     torch.cuda.synchronize()
     return ev0.elapsed_time(ev1) / reps
@@ -126,6 +136,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline configuration: no CPU leg, no other key mode / storage lines (profiling runs, "
+                         "so that a kernel name in the profile is one configuration)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,9 +171,11 @@ def main():
             autoreset=True, reward_shaping=True, env_rng=env_rng, sync_rewards=False, genetic_map=gm, **kw,
         )
 
-    # Headline: the drop-in configuration.  env_rng="shared" is what the reference computes -- its
-    # jax.vmap over an un-batched simulator key hands every env the same gamete keys
+    # Headline: the drop-in configuration, all defaults.  env_rng="shared" is what the reference
+    # computes -- its jax.vmap over an un-batched simulator key hands every env the same gamete keys
     # (vec_env.py:75-77) -- so per step the Threefry work is n x 2 gametes, applied to E x n crosses.
+    # storage="bits" (default): the populations live as bit planes between steps; every step still
+    # writes and returns the byte-layout observation (observations="eager").
     env = make_env("shared")
     dev = env.device
     arng = np.random.default_rng(2 + rank)
@@ -185,25 +200,28 @@ def main():
 
     # The same steps with an independent Threefry stream per cross (an extension: not what the
     # reference computes).  VALU-bound: 2 x 10k x 36 integer ops per cross.
-    env_i = make_env("independent")
-    env_i.reset(seed=100 + rank)
-    dt_i = time_steps(env_i, actions, args.steps, args.warmup, barrier)
-    ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(ti, op=dist.ReduceOp.MAX)
-    kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
+    ti = kern_ms_i = None
+    if not args.headline_only:
+        env_i = make_env("independent")
+        env_i.reset(seed=100 + rank)
+        dt_i = time_steps(env_i, actions, args.steps, args.warmup, barrier)
+        ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+        kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
 
-    # Populations kept as bit planes between steps: same observations when they are
-    # written eagerly, a handle that expands on demand when they are not.  One GPU only: extra lines,
-    # not the headline.
-    bits = {}
-    if world == 1:
-        for obs in ("eager", "lazy"):
-            env_b = make_env("shared", storage="bits", observations=obs)
-            env_b.reset(seed=100 + rank)
-            dt_b = time_steps(env_b, actions, args.steps, args.warmup, barrier)
-            bits[obs] = {"value": args.steps * N_ENVS * N_PER_ENV / dt_b, "ms_per_step": dt_b / args.steps * 1e3}
-            del env_b
+    # The other storage / observation choices of the same env, same outputs (one GPU only: extra
+    # lines, not the headline): byte-layout state, and bit planes with on-demand observations.
+    variants = {}
+    if world == 1 and not args.headline_only:
+        for name, kw in (("byte_layout_storage", dict(storage="bytes")),
+                         ("lazy_observations", dict(storage="bits", observations="lazy"))):
+            env_v = make_env("shared", **kw)
+            env_v.reset(seed=100 + rank)
+            dt_v = time_steps(env_v, actions, args.steps, args.warmup, barrier)
+            variants[name] = {"value": args.steps * N_ENVS * N_PER_ENV / dt_v, "ms_per_step": dt_v / args.steps * 1e3,
+                              "kernel_ms": time_cross_launches(env_v, actions, max(20, args.steps))}
+            del env_v
 
     # algorithmic bytes per launch: 2 parents x 2M read + 2M written per cross
     alg_bytes = 6 * N_MARKERS * crosses_per_step
@@ -235,30 +253,32 @@ def main():
                             "every step, 10-generation episodes with autoreset",
                 "n_markers": N_MARKERS, "crosses_per_step_per_gpu": crosses_per_step,
                 "env_rng": "shared (reference semantics: vmap over an un-batched key, vec_env.py:75-77)",
+                "storage": "bits (default): 1 bit per allele between steps, byte-layout observation written every step",
                 "sharding": "envs across ranks, no data-path collective",
             },
             "roofline": {
-                "kernel": "cross_kernel<TT=1,MW=4,R=2> (row role: gather+select+GEBV stream, 2 rows per wave; mask role: next generation's Threefry)",
+                "kernel": "packed_cross_kernel<TT=1,MW=4,R=2> (row role: bit-plane parents -> select -> byte-layout "
+                          "observation + bit-plane state + GEBV, 2 rows per wave; mask role: next generation's Threefry)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                 "kernel_crosses_per_s": crosses_per_step / (kern_ms * 1e-3),
             },
-            "independent_rng": {
+        }
+        if ti is not None:
+            line["independent_rng"] = {
                 "note": "one Threefry stream per cross (env_rng='independent', an extension); VALU-bound",
                 "value": world * args.steps * crosses_per_step / float(ti.item()),
                 "ms_per_step": float(ti.item()) / args.steps * 1e3,
                 "kernel_ms": kern_ms_i,
                 "achieved_GBps": alg_bytes / (kern_ms_i * 1e-3) / 1e9,
-            },
-        }
-        if bits:
-            line["bit_plane_storage"] = {
-                "note": "storage='bits': populations live as 1 bit per allele between steps; 'eager' also writes the "
-                        "byte-layout observation in the same launch, 'lazy' hands out a handle that expands on demand",
-                **bits,
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if variants:
+            variants["byte_layout_storage"]["note"] = "storage='bytes': the byte layout is the state; cross_kernel<1,4,2>"
+            variants["lazy_observations"]["note"] = ("storage='bits', observations='lazy': the step hands out a handle "
+                                                      "that expands to the byte layout on demand")
+            line.update(variants)
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline(gm, geno, 0)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

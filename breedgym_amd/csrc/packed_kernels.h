@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t gamete8(uint32_t p16, uint32_t z8) {
 // them, as in row_role); MODE_CROSS or MODE_GATHER.  The loop is deliberately plain: requesting the
 // next trips' words ahead of the current trip's stores (software pipelining) was measured -- it costs
 // registers the mask role next door needs more than the row role needs the overlap.
-template <int TT, int MODE, int R>
+template <int TT, int MODE, int R, int PRIO = 3>
 __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int block, const int wave) {
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   constexpr int NT = TT > 0 ? TT : 1;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
     dstp[r] = (p.outp && live[r]) ? p.outp + (int64_t)c * p.nvp : nullptr;
     dstb[r] = (p.outb && live[r]) ? p.outb + (int64_t)c * p.pitch : nullptr;
   }
-  __builtin_amdgcn_s_setprio(3);
+  if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);  // see row_role
 
   double acc[R][NT];
 #pragma unroll
@@ -168,6 +168,122 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
   }
 }
 
+// The row role of the fused launch next to four-wave mask groups, software-pipelined like
+// row_role_pipelined (row_kernels.h): the 2-byte words of trip t+1 are requested before trip t's
+// stores and the marker effects of trip t before those, no wait covers a store, the body is
+// branch-free (lanes past the end of the row redo the last vector, dead row slots redo row c0; the few
+// padding words of a packed row are written behind the loop), no priority raise.
+template <int TT, int R, bool OBS>
+__device__ __forceinline__ void packed_cross_role(const PackedParams &p, const int block, const int wave) {
+  static_assert(TT == 1 || TT == 2, "effects are held in registers across the trip");
+  const int lane = threadIdx.x & 63;
+  const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
+  if (c0 >= p.n_rows) return;
+
+  const uint16_t *src0[R], *src1[R], *Z16[R];
+  uint16_t *dstp[R];
+  uint8_t *dstb[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    live[r] = c0 + r < p.n_rows;
+    const int c = live[r] ? c0 + r : c0;
+    const int e = c / p.n_out, i = c - e * p.n_out;
+    const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
+    const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
+    src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
+    src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
+    Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
+    dstp[r] = p.outp + (int64_t)c * p.nvp;
+    dstb[r] = OBS ? p.outb + (int64_t)c * p.pitch : nullptr;
+  }
+
+  double acc[R][TT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[r][t] = 0.0;
+
+  const int last = p.nvec - 1;
+  struct Words {
+    uint32_t a[R], b[R], z[R];
+  };
+  auto load_words = [&](int base, Words &w) {
+    int v = base + lane;
+    v = v < last ? v : last;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      w.a[r] = src0[r][v];
+      w.b[r] = src1[r][v];
+      w.z[r] = Z16[r][v];
+    }
+  };
+  auto trip = [&](int base, const Words &w, Words &next) {
+    const int v = base + lane;
+    const bool has = v < p.nvec;
+    const int vv = v < last ? v : last;
+    double2 ef[TT][4];
+#pragma unroll
+    for (int q = 0; q < TT; ++q) {
+      const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)q * p.effPitch + 8 * (int64_t)vv);
+      ef[q][0] = ep[0];
+      ef[q][1] = ep[1];
+      ef[q][2] = ep[2];
+      ef[q][3] = ep[3];
+    }
+    load_words(base + 64, next);
+    uint4 oo[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t o = gamete8(w.a[r], w.z[r] & 0xffu) | (gamete8(w.b[r], w.z[r] >> 8) << 8);
+      dstp[r][vv] = (uint16_t)o;
+      oo[r] = expand_vector(o);
+      if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)vv) = oo[r];
+    }
+    if (has) {  // a lane that redid the last vector must not count it twice
+#pragma unroll
+      for (int q = 0; q < TT; ++q) {
+        const double e[8] = {ef[q][0].x, ef[q][0].y, ef[q][1].x, ef[q][1].y, ef[q][2].x, ef[q][2].y, ef[q][3].x, ef[q][3].y};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const Dosage8 d = dosages(oo[r]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[r][q] = fma(d.d[k], e[k], acc[r][q]);
+        }
+      }
+    }
+  };
+  Words wa, wb;
+  load_words(0, wa);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending (row_role_pipelined)
+  for (int base = 0; base < p.nvec; base += 128) {  // two trips per turn, no branch between them
+    trip(base, wa, wb);
+    trip(base + 64, wb, wa);
+  }
+  if (p.nvec + lane < p.nvp) {  // padding words: markers beyond M, up to the next multiple of 64
+#pragma unroll
+    for (int r = 0; r < R; ++r) dstp[r][p.nvec + lane] = 0;
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      double s = acc[r][t];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      acc[r][t] = s;
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (live[r]) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
+      }
+  }
+}
+
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   packed_row_role<TT, MODE, R>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6));
@@ -193,7 +309,20 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
   if (wave >= 4) return;
 #endif
   if (wave < 4) {
-    if ((int)blockIdx.x < rp.n_blocks) packed_row_role<TT, MODE_CROSS, R>(rp, (int)blockIdx.x, wave);
+    if ((int)blockIdx.x < rp.n_blocks) {
+#if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
+      if constexpr ((TT == 1 || TT == 2) && MW == 4) {
+        if (rp.zpitch <= 4096) {  // rows of up to 16384 markers; longer ones gain nothing from it
+          if (rp.outb)
+            packed_cross_role<TT, R, true>(rp, (int)blockIdx.x, wave);
+          else
+            packed_cross_role<TT, R, false>(rp, (int)blockIdx.x, wave);
+          return;
+        }
+      }
+#endif
+      packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave);
+    }
   } else if constexpr (MW == 1) {
     if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
   } else {

@@ -349,7 +349,7 @@ __device__ __forceinline__ Dosage8 dosages(const uint4 o) {
 // loaded once and applied to all R rows (with one row per wave the effects were 2x the genotype
 // bytes out of L2).  R > 1 only with WAVES == 1.
 // LONG rows (HBM-resident sets) want more loads in flight: two vectors per row and trip.
-template <int WAVES, int TT, int MODE, int R, bool LONG>
+template <int WAVES, int TT, int MODE, int R, bool LONG, int PRIO = 3>
 __device__ __forceinline__ void row_role(const RowParams &p, const int block, const int wave, double *red) {
   static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or the whole workgroup");
   static_assert(R == 1 || WAVES == 1, "several rows per group only for one-wave groups");
@@ -388,10 +388,13 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
     dst[r] = (MODE == MODE_GEBV) ? nullptr : p.out + (int64_t)c * p.pitch;
   }
 
-  // Row waves share their SIMD with a VALU-bound mask wave.  VALU issue is arbitrated by
-  // priority first: the little arithmetic a row wave has between its loads should not queue
-  // behind Threefry, or the memory pipes drain.
-  __builtin_amdgcn_s_setprio(3);
+  // Row waves share their SIMD with VALU-bound mask waves, and VALU issue is arbitrated by priority
+  // first.  Next to one-wave-per-cross mask groups (many keyed crosses: the launch is Threefry-bound)
+  // the little arithmetic a row wave has between its loads must not queue behind Threefry, or the
+  // memory pipes drain: PRIO 3.  Next to four-wave mask groups (few keyed crosses: the launch is
+  // bound by the streaming) equal priority lets the mask waves use the row waves' stalls instead of
+  // being held to the end: PRIO 0 (measured: profiles/r01_ab_row_pipelined_priority.txt).
+  if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
 
   // NC independent chains per sum.  Long rows (HBM-resident sets, few waves per SIMD doing the sums)
   // gain 8 % from four chains -- a single chain of dependent f64 FMAs waits out the FMA latency
@@ -508,6 +511,127 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
   }
 }
 
+// The row role of the fused launch for short rows next to four-wave mask groups (few keyed crosses:
+// the reference's shared keys), software-pipelined.  gfx950 counts loads and
+// stores in one in-order counter (vmcnt): a trip that loads after it stored can only wait for that
+// load by also waiting for the store to be acknowledged.  Here the genotype vectors and mask words of
+// trip t+1 are requested before trip t's stores, and the marker effects of trip t before those, so
+// that no wait covers a store; only the genotype registers exist twice (18 VGPRs for two rows).  The
+// body is branch-free so that the compiler's counter model stays exact: lanes past the end of the row
+// redo the last vector, dead row slots redo row c0 -- the same bytes stored twice.
+template <int TT, int R>
+__device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int block, const int wave) {
+  static_assert(TT == 1 || TT == 2, "effects are held in registers across the trip");
+  const int lane = threadIdx.x & 63;
+  const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
+  if (c0 >= p.n_rows) return;
+
+  const uint8_t *src0[R], *src1[R];
+  const uint16_t *Z16[R];
+  uint8_t *dst[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    live[r] = c0 + r < p.n_rows;
+    const int c = live[r] ? c0 + r : c0;
+    const int e = c / p.n_out, i = c - e * p.n_out;
+    const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
+    const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
+    src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.pitch;
+    src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.pitch;
+    Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
+    dst[r] = p.out + (int64_t)c * p.pitch;
+  }
+  // no s_setprio: next to four-wave mask groups, see row_role
+
+  double acc[R][TT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[r][t] = 0.0;
+
+  const int last = p.nvec - 1;
+  struct Vecs {
+    uint4 a[R], b[R];
+    uint32_t z[R];
+  };
+  auto load_vecs = [&](int base, Vecs &w) {
+    int v = base + lane;
+    v = v < last ? v : last;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      w.a[r] = *reinterpret_cast<const uint4 *>(src0[r] + 16 * (int64_t)v);
+      w.b[r] = *reinterpret_cast<const uint4 *>(src1[r] + 16 * (int64_t)v);
+      w.z[r] = Z16[r][v];
+    }
+  };
+  auto trip = [&](int base, const Vecs &w, Vecs &next) {
+    const int v = base + lane;
+    const bool has = v < p.nvec;
+    const int vv = v < last ? v : last;
+    double2 ef[TT][4];
+#pragma unroll
+    for (int q = 0; q < TT; ++q) {
+      const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)q * p.effPitch + 8 * (int64_t)vv);
+      ef[q][0] = ep[0];
+      ef[q][1] = ep[1];
+      ef[q][2] = ep[2];
+      ef[q][3] = ep[3];
+    }
+    load_vecs(base + 64, next);
+    uint4 oo[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint4 o;
+      o.x = select_dword(w.z[r], 0, w.a[r].x, w.b[r].x);
+      o.y = select_dword(w.z[r], 1, w.a[r].y, w.b[r].y);
+      o.z = select_dword(w.z[r], 2, w.a[r].z, w.b[r].z);
+      o.w = select_dword(w.z[r], 3, w.a[r].w, w.b[r].w);
+      *reinterpret_cast<uint4 *>(dst[r] + 16 * (int64_t)vv) = o;
+      oo[r] = o;
+    }
+    if (has) {  // a lane that redid the last vector must not count it twice
+#pragma unroll
+      for (int q = 0; q < TT; ++q) {
+        const double e[8] = {ef[q][0].x, ef[q][0].y, ef[q][1].x, ef[q][1].y, ef[q][2].x, ef[q][2].y, ef[q][3].x, ef[q][3].y};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const Dosage8 d = dosages(oo[r]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[r][q] = fma(d.d[k], e[k], acc[r][q]);
+        }
+      }
+    }
+  };
+  Vecs wa, wb;
+  load_vecs(0, wa);
+  // enter the loop with nothing pending, so that the loop head inherits the back edge's wait ("the
+  // vectors, but not the stores behind them") rather than its merge with "the loads just issued"
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int base = 0; base < p.nvec; base += 128) {  // two trips per turn, no branch between them
+    trip(base, wa, wb);
+    trip(base + 64, wb, wa);
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      double s = acc[r][t];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      acc[r][t] = s;
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (live[r]) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
+      }
+  }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(256) void mask_kernel(const MaskParams p) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
@@ -547,7 +671,14 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
   if (wave >= 4) return;
 #endif
   if (wave < 4) {
-    if ((int)blockIdx.x < rp.n_blocks) row_role<1, TT, MODE_CROSS, R, LONG>(rp, (int)blockIdx.x, wave, nullptr);
+    if ((int)blockIdx.x < rp.n_blocks) {
+#if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
+      if constexpr ((TT == 1 || TT == 2) && !LONG && MW == 4)
+        row_role_pipelined<TT, R>(rp, (int)blockIdx.x, wave);
+      else
+#endif
+        row_role<1, TT, MODE_CROSS, R, LONG, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, nullptr);
+    }
   } else if constexpr (MW == 1) {
     if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
   } else {

@@ -15,11 +15,13 @@ Differences a caller can see, all opt-in or benign:
     ``"shared"`` reproduces the reference, whose ``jax.vmap`` over an un-batched simulator key
     (vec_env.py:75-77) hands all envs the same gamete keys;
   * ``sync_rewards=False`` returns the reward vector as a device array and so never blocks;
-  * ``storage="bits"`` keeps the populations between steps as bit-plane rows (1 bit per allele, 8x
-    less HBM and 8x less to read per cross).  The observation handed out
-    is unchanged -- the same launch also writes the byte-layout offspring -- unless
+  * ``storage="bits"`` (the default) keeps the populations between steps as bit-plane rows (1 bit per
+    allele, 8x less HBM and 8x less to read per cross).  The observation
+    handed out is unchanged -- the same launch also writes the byte-layout offspring -- unless
     ``observations="lazy"``, which returns a ``PackedPopulation`` handle that expands on demand
     (``env.populations``, ``np.asarray(obs)``), for policies that only look at ``infos["GEBV"]``.
+    ``storage="bytes"`` keeps the byte layout as the state (the step then reads 4M bytes of parents per
+    cross instead of M/2; same results, bit for bit).
 """
 from pathlib import Path
 from typing import Optional, Tuple, Union
@@ -54,7 +56,7 @@ class VecBreedGym(_VectorEnvBase):
         reward_shaping: bool = False,
         env_rng: str = "shared",
         sync_rewards: bool = True,
-        storage: str = "bytes",
+        storage: str = "bits",
         observations: str = "eager",
         **kwargs,
     ):

@@ -247,7 +247,7 @@ def test_vec_env_bit_plane_storage(observations, env_rng):
     geno = synthetic_genotypes(50, 1300, seed=4)
     kw = dict(num_envs=5, initial_population=geno, genetic_map=gm, individual_per_gen=24, num_generations=4,
               reward_shaping=True, env_rng=env_rng)
-    ref = VecBreedGym(**kw)
+    ref = VecBreedGym(storage="bytes", **kw)
     env = VecBreedGym(storage="bits", observations=observations, **kw)
     p0, i0 = ref.reset(seed=5)
     p1, i1 = env.reset(seed=5)

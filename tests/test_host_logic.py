@@ -396,7 +396,7 @@ def test_vec_bit_plane_storage_is_invisible(data, observations, env_rng):
     from breedgym_amd import PackedPopulation
 
     kw = dict(num_envs=3, individual_per_gen=10, num_generations=4, reward_shaping=True, env_rng=env_rng)
-    ref = make_vec(data, **kw)
+    ref = make_vec(data, storage="bytes", **kw)
     env = make_vec(data, storage="bits", observations=observations, **kw)
     p0, i0 = ref.reset(seed=11)
     p1, i1 = env.reset(seed=11)
@@ -419,7 +419,7 @@ def test_vec_bit_plane_storage_is_invisible(data, observations, env_rng):
     a = rng.integers(0, 10, (3, 10, 2)).astype(np.int32)
     assert np.array_equal(np.asarray(env.step(a)[0]), np.asarray(ref.step(a)[0]))
     with pytest.raises(ValueError):
-        make_vec(data, observations="lazy")
+        make_vec(data, storage="bytes", observations="lazy")
     with pytest.raises(ValueError):
         make_vec(data, storage="nibbles")
 
