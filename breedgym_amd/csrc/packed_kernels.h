@@ -168,14 +168,16 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
   }
 }
 
-// The row role of the fused launch next to four-wave mask groups, software-pipelined like
+// The row role of the fused launch next to four-wave mask groups, and the stream of the standalone
+// launches that write packed rows with their GEBV (reset's founder gather), software-pipelined like
 // row_role_pipelined (row_kernels.h): the 2-byte words of trip t+1 are requested before trip t's
 // stores and the marker effects of trip t before those, no wait covers a store, the body is
 // branch-free (lanes past the end of the row redo the last vector, dead row slots redo row c0; the few
 // padding words of a packed row are written behind the loop), no priority raise.
-template <int TT, int R, bool OBS>
-__device__ __forceinline__ void packed_cross_role(const PackedParams &p, const int block, const int wave) {
+template <int TT, int MODE, int R, bool OBS>
+__device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave) {
   static_assert(TT == 1 || TT == 2, "effects are held in registers across the trip");
+  static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   const int lane = threadIdx.x & 63;
   const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
   if (c0 >= p.n_rows) return;
@@ -188,12 +190,18 @@ __device__ __forceinline__ void packed_cross_role(const PackedParams &p, const i
   for (int r = 0; r < R; ++r) {
     live[r] = c0 + r < p.n_rows;
     const int c = live[r] ? c0 + r : c0;
-    const int e = c / p.n_out, i = c - e * p.n_out;
-    const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
-    const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
-    src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
-    src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
-    Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
+    src1[r] = nullptr;
+    Z16[r] = nullptr;
+    if constexpr (MODE == MODE_CROSS) {
+      const int e = c / p.n_out, i = c - e * p.n_out;
+      const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
+      const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
+      src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
+      src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
+      Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
+    } else {
+      src0[r] = p.src + (int64_t)(p.idx ? norm_index(p.idx[c], p.n_pool) : c) * p.nvp;
+    }
     dstp[r] = p.outp + (int64_t)c * p.nvp;
     dstb[r] = OBS ? p.outb + (int64_t)c * p.pitch : nullptr;
   }
@@ -214,8 +222,13 @@ __device__ __forceinline__ void packed_cross_role(const PackedParams &p, const i
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       w.a[r] = src0[r][v];
-      w.b[r] = src1[r][v];
-      w.z[r] = Z16[r][v];
+      if constexpr (MODE == MODE_CROSS) {
+        w.b[r] = src1[r][v];
+        w.z[r] = Z16[r][v];
+      } else {
+        w.b[r] = 0;
+        w.z[r] = 0;
+      }
     }
   };
   auto trip = [&](int base, const Words &w, Words &next) {
@@ -235,7 +248,8 @@ __device__ __forceinline__ void packed_cross_role(const PackedParams &p, const i
     uint4 oo[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t o = gamete8(w.a[r], w.z[r] & 0xffu) | (gamete8(w.b[r], w.z[r] >> 8) << 8);
+      uint32_t o = w.a[r];
+      if constexpr (MODE == MODE_CROSS) o = gamete8(w.a[r], w.z[r] & 0xffu) | (gamete8(w.b[r], w.z[r] >> 8) << 8);
       dstp[r][vv] = (uint16_t)o;
       oo[r] = expand_vector(o);
       if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)vv) = oo[r];
@@ -286,7 +300,19 @@ __device__ __forceinline__ void packed_cross_role(const PackedParams &p, const i
 
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
-  packed_row_role<TT, MODE, R>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6));
+  const int wave = (int)(threadIdx.x >> 6);
+  if constexpr (TT == 1 || TT == 2) {
+    // packed rows out, GEBV wanted, rows of up to 16384 markers (reset's founder gather, a cross
+    // without run-ahead): the pipelined stream
+    if (p.outp && p.zpitch <= 4096) {
+      if (p.outb)
+        packed_stream_role<TT, MODE, R, true>(p, (int)blockIdx.x, wave);
+      else
+        packed_stream_role<TT, MODE, R, false>(p, (int)blockIdx.x, wave);
+      return;
+    }
+  }
+  packed_row_role<TT, MODE, R>(p, (int)blockIdx.x, wave);
 }
 
 // cross_kernel (row_kernels.h) with the packed row role: waves 0-3 stream generation g, waves 4-7
@@ -314,9 +340,9 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
       if constexpr ((TT == 1 || TT == 2) && MW == 4) {
         if (rp.zpitch <= 4096) {  // rows of up to 16384 markers; longer ones gain nothing from it
           if (rp.outb)
-            packed_cross_role<TT, R, true>(rp, (int)blockIdx.x, wave);
+            packed_stream_role<TT, MODE_CROSS, R, true>(rp, (int)blockIdx.x, wave);
           else
-            packed_cross_role<TT, R, false>(rp, (int)blockIdx.x, wave);
+            packed_stream_role<TT, MODE_CROSS, R, false>(rp, (int)blockIdx.x, wave);
           return;
         }
       }
