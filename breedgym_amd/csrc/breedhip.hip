@@ -76,6 +76,7 @@ struct bh_ctx {
   // fixed-point marker effects for the int8-MFMA GEBV: one pack per group of <= 10 traits
   std::vector<bh::i32x4 *> d_Bpack;
   double *d_scale = nullptr;  // (T) 2^-s_t
+  uint4 *d_dig16 = nullptr;   // (T, nvec, 3) int16 digit planes of the fixed-point effects (packed_kernels.h)
   int32_t n_chunks = 0;
   int32_t *d_partial = nullptr;
   int64_t partial_cap = 0;  // int32 words
@@ -321,6 +322,8 @@ bh::RowParams base_params(const bh_ctx *c) {
 bh::PackedParams packed_params(const bh_ctx *c) {
   bh::PackedParams p{};
   p.eff = c->d_eff;
+  p.dig = c->d_dig16;
+  p.scale = c->d_scale;
   p.pitch = c->pitch;
   p.effPitch = c->effPitch;
   p.zpitch = (int64_t)16 * c->nw;
@@ -554,6 +557,21 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
     }
     BH_HIP_C(hipMalloc(&c->d_scale, (size_t)n_traits * sizeof(double)));
     BH_HIP_C(hipMemcpy(c->d_scale, scale.data(), (size_t)n_traits * sizeof(double), hipMemcpyHostToDevice));
+    {  // the same fixed-point effects as three balanced base-65536 digits, 8 markers (one vector) per 16 bytes
+      std::vector<int16_t> dig((size_t)n_traits * c->nvec * 3 * 8, (int16_t)0);
+      for (int64_t t = 0; t < n_traits; ++t)
+        for (int64_t m = 0; m < n_markers; ++m) {
+          long long fix = std::llround(std::ldexp((double)effects[m * n_traits + t], shift[(size_t)t]));
+          for (int j = 0; j < 3; ++j) {
+            long long d = ((fix % 65536) + 65536) % 65536;
+            if (d >= 32768) d -= 65536;
+            fix = (fix - d) / 65536;
+            dig[(size_t)(((t * c->nvec + (m >> 3)) * 3 + j) * 8 + (m & 7))] = (int16_t)d;
+          }
+        }
+      BH_HIP_C(hipMalloc(&c->d_dig16, dig.size() * sizeof(int16_t)));
+      BH_HIP_C(hipMemcpy(c->d_dig16, dig.data(), dig.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    }
     const int64_t packs = (n_traits + kTraitsPerPack - 1) / kTraitsPerPack;
     std::vector<int8_t> pack((size_t)c->n_chunks * 4096);
     for (int64_t g = 0; g < packs; ++g) {
@@ -595,6 +613,7 @@ int bh_destroy(bh_ctx *c) {
   for (auto *b : c->d_Bpack)
     if (b) (void)hipFree(b);
   if (c->d_scale) (void)hipFree(c->d_scale);
+  if (c->d_dig16) (void)hipFree(c->d_dig16);
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);

@@ -26,6 +26,8 @@ struct PackedParams {
   float *gebv;          // (rows, T) or null
   const uint8_t *Z;     // cross: (B, zpitch) masks from the mask role
   const double *eff;    // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
+  const uint4 *dig;     // (T, nvec, 3) 16-byte blocks: digit j of trait t for the 8 markers of vector v, as int16
+  const double *scale;  // (T) 2^-s_t of the fixed-point effects
   int64_t pitch;        // bytes per byte-layout row
   int64_t effPitch;
   int64_t zpitch;       // bytes per mask row = bytes per packed row = 16 * nw
@@ -206,11 +208,26 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     dstb[r] = OBS ? p.outb + (int64_t)c * p.pitch : nullptr;
   }
 
+#if defined(BH_GEBV_F64)  // tuning experiments only: the f64 sum of the plain roles
   double acc[R][TT];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int t = 0; t < TT; ++t) acc[r][t] = 0.0;
+#else
+  // GEBV in exact fixed point: the effects are round(e * 2^s_t) cut into three balanced base-65536
+  // digits (as gebv_mfma.h cuts them into six base-256 ones), the dosages of a marker pair are the
+  // two int16 halves of (w + (w >> 8)) & 0x00FF00FF, and a v_dot2_i32_i16 per pair and digit replaces
+  // eight conversions and eight f64 FMAs per vector.  |digit| <= 2^15 and dosage <= 2, so a lane's
+  // int32 sums stay below 2^31 for rows of up to 2^17 markers.
+  int acc[R][TT][3];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[r][t][j] = 0;
+#endif
 
   const int last = p.nvec - 1;
   struct Words {
@@ -235,6 +252,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     const int v = base + lane;
     const bool has = v < p.nvec;
     const int vv = v < last ? v : last;
+#if defined(BH_GEBV_F64)
     double2 ef[TT][4];
 #pragma unroll
     for (int q = 0; q < TT; ++q) {
@@ -244,6 +262,16 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       ef[q][2] = ep[2];
       ef[q][3] = ep[3];
     }
+#else
+    uint4 dg[TT][3];
+#pragma unroll
+    for (int q = 0; q < TT; ++q) {
+      const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
+      dg[q][0] = dp[0];
+      dg[q][1] = dp[1];
+      dg[q][2] = dp[2];
+    }
+#endif
     load_words(base + 64, next);
     uint4 oo[R];
 #pragma unroll
@@ -255,6 +283,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)vv) = oo[r];
     }
     if (has) {  // a lane that redid the last vector must not count it twice
+#if defined(BH_GEBV_F64)
 #pragma unroll
       for (int q = 0; q < TT; ++q) {
         const double e[8] = {ef[q][0].x, ef[q][0].y, ef[q][1].x, ef[q][1].y, ef[q][2].x, ef[q][2].y, ef[q][3].x, ef[q][3].y};
@@ -265,6 +294,27 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           for (int k = 0; k < 8; ++k) acc[r][q] = fma(d.d[k], e[k], acc[r][q]);
         }
       }
+#else
+      typedef short short2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t w[4] = {oo[r].x, oo[r].y, oo[r].z, oo[r].w};
+        uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pr[k] = (w[k] + (w[k] >> 8)) & 0x00FF00FFu;
+#pragma unroll
+        for (int q = 0; q < TT; ++q)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const uint32_t dd[4] = {dg[q][j].x, dg[q][j].y, dg[q][j].z, dg[q][j].w};
+            int a = acc[r][q][j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
+            acc[r][q][j] = a;
+          }
+      }
+#endif
     }
   };
   Words wa, wb;
@@ -279,6 +329,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     for (int r = 0; r < R; ++r) dstp[r][p.nvec + lane] = 0;
   }
 
+#if defined(BH_GEBV_F64)
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -296,6 +347,18 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         for (int t = 0; t < TT; ++t) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
       }
   }
+#else
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      // digits recombined in int64 per lane, then summed over the wave: exact, order-free
+      long long s = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0 && live[r]) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)((double)s * p.scale[p.t0 + t]);
+    }
+#endif
 }
 
 template <int TT, int MODE, int R>
