@@ -1,15 +1,15 @@
-// Bit-plane genotype rows: 1 bit per allele, 8x less to read than the byte layout of the API.
+// Bit-packed genotype rows: 1 bit per allele, 8x less to read than the byte layout of the API.
 //
-// A packed row is uint16 P[8 * nw] (nw = ceil(M / 64)): P[v] describes markers 8v .. 8v+7, low byte =
-// their allele-0 bits, high byte = their allele-1 bits (bit t = marker 8v + t); bits of markers
-// >= M are zero.  That is the shape of the crossover-mask rows mask_kernel writes (low byte =
-// gamete 0, high byte = gamete 1), and P[v] is exactly what one lane needs to produce the 16-byte
-// vector v of the byte layout -- so the row role of a cross becomes
+// A packed row is uint16 P[8 * nw] (nw = ceil(M / 64)): bit i of P[v] is byte i of the 16-byte vector
+// v of the byte-layout row -- markers 8v .. 8v+7, even bits their allele 0, odd bits their allele 1
+// (numpy: packbits(row_bytes, bitorder="little") viewed as uint16); bits of markers >= M are zero.
+// That is also the shape of the crossover-mask rows the mask role writes (even bits: gamete 0 = the
+// mask for parent 0, odd bits: gamete 1), and P[v] is exactly what one lane needs to produce vector v
+// -- so the row role of a cross becomes
 //     three 2-byte loads (parent 0, parent 1, mask)  ->  8+8 bit selects  ->  2-byte store
 //     [-> 16-byte coalesced store of the byte-layout offspring, if the caller wants observations]
-//     [-> f64 GEBV from the expanded vector, as in row_kernels.h]
-// Per cross that is M/2 + M/4 bytes read and M/4 (+ 2M) written instead of 4M read and 2M written;
-// with byte observations on, the launch is bound by the 2M-byte store alone.
+//     [-> GEBV from the expanded vector]
+// Per cross that is M/2 + M/4 bytes read and M/4 (+ 2M) written instead of 4M read and 2M written.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,22 +40,25 @@ struct PackedParams {
   int32_t rng_shared;
 };
 
-// dword k of byte-layout vector v from its packed word: bytes [a0(2k), a1(2k), a0(2k+1), a1(2k+1)].
-// nib = [a0(2k) a0(2k+1) a1(2k) a1(2k+1)]; the multiply drops its bits onto bit 0 of bytes 0, 2, 1, 3.
+// dword k of byte-layout vector v from its packed word: bits 4k .. 4k+3 are its four bytes; the
+// multiply drops them onto bit 0 of bytes 0, 1, 2, 3.
 __device__ __forceinline__ uint32_t expand_dword(uint32_t o16, int k) {
-  const uint32_t nib = ((o16 >> (2 * k)) & 3u) | (((o16 >> (8 + 2 * k)) & 3u) << 2);
-  return (nib * 0x00208041u) & 0x01010101u;
+  return (((o16 >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u;
 }
 
 __device__ __forceinline__ uint4 expand_vector(uint32_t o16) {
   return make_uint4(expand_dword(o16, 0), expand_dword(o16, 1), expand_dword(o16, 2), expand_dword(o16, 3));
 }
 
-// the gamete a parent passes on, for 8 markers at once: allele-0 bit where the mask bit is 0,
-// allele-1 bit where it is 1
-__device__ __forceinline__ uint32_t gamete8(uint32_t p16, uint32_t z8) {
-  const uint32_t lo = p16 & 0xffu, hi = p16 >> 8;
-  return lo ^ ((lo ^ hi) & z8);
+// The offspring word of a cross, 8 markers at once.  Allele 0 of the offspring is the gamete of
+// parent 0: its allele-0 bit (even position) where the mask bit is 0, its allele-1 bit where it is 1;
+// allele 1 is the gamete of parent 1 under the odd mask bits.
+__device__ __forceinline__ uint32_t cross16(uint32_t p0, uint32_t p1, uint32_t z) {
+  const uint32_t e0 = p0 & 0x5555u, o0 = (p0 >> 1) & 0x5555u;
+  const uint32_t e1 = p1 & 0x5555u, o1 = (p1 >> 1) & 0x5555u;
+  const uint32_t g0 = e0 ^ ((e0 ^ o0) & z);         // even bits; z's odd bits fall on zeros
+  const uint32_t g1 = e1 ^ ((e1 ^ o1) & (z >> 1));  // even bits
+  return g0 | (g1 << 1);
 }
 
 // One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
@@ -116,7 +119,7 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       uint32_t o = a[r];
-      if constexpr (MODE == MODE_CROSS) o = gamete8(a[r], z[r] & 0xffu) | (gamete8(b[r], z[r] >> 8) << 8);
+      if constexpr (MODE == MODE_CROSS) o = cross16(a[r], b[r], z[r]);
       if (dstp[r]) dstp[r][v] = (uint16_t)o;
       oo[r] = expand_vector(o);
       if (dstb[r] && inrow) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)v) = oo[r];
@@ -277,7 +280,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       uint32_t o = w.a[r];
-      if constexpr (MODE == MODE_CROSS) o = gamete8(w.a[r], w.z[r] & 0xffu) | (gamete8(w.b[r], w.z[r] >> 8) << 8);
+      if constexpr (MODE == MODE_CROSS) o = cross16(w.a[r], w.b[r], w.z[r]);
       dstp[r][vv] = (uint16_t)o;
       oo[r] = expand_vector(o);
       if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)vv) = oo[r];
@@ -440,12 +443,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
       const uint4 w = *reinterpret_cast<const uint4 *>(s + 16 * (int64_t)v);
       const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // bit 0 of bytes 0..3 -> bits 0..3: [a0(2k), a1(2k), a0(2k+1), a1(2k+1)]
-        const uint32_t nib = ((dw[k] & 0x01010101u) * 0x01020408u) >> 24;
-        o |= ((nib & 1u) | ((nib >> 1) & 2u)) << (2 * k);
-        o |= (((nib >> 1) & 1u) | ((nib >> 2) & 2u)) << (8 + 2 * k);
-      }
+      for (int k = 0; k < 4; ++k)  // bit 0 of bytes 0..3 -> bits 4k .. 4k+3
+        o |= (((dw[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);
     }
     d[v] = (uint16_t)o;
   }

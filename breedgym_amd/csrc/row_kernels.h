@@ -6,7 +6,7 @@
 //     cross; the Bernoulli(r) recombination sites leave the wave as ballots -> 64-bit site
 //     words in LDS (phase A); an inclusive prefix-XOR over the site strings (6 shift-xor steps
 //     inside a 64-bit word, ballot+popcount across words) turns them into crossover masks,
-//     written to HBM byte-interleaved, 2 bits per marker = M/4 bytes per cross (phase B).
+//     written to HBM bit-interleaved, 2 bits per marker = M/4 bytes per cross (phase B).
 //     One Threefry call serves two markers (JAX's original random_bits layout hashes the
 //     counter vector in two halves) and each threshold load is shared by the two gametes.
 //     The masks depend on the key chain and the cross slot only -- not on the parents -- so
@@ -35,7 +35,7 @@ namespace bh {
 enum { MODE_CROSS = 0, MODE_GATHER = 1, MODE_GEBV = 2 };
 
 struct MaskParams {
-  uint8_t *Z;            // (n_rows, zpitch) interleaved crossover masks, out
+  uint8_t *Z;            // (n_rows, zpitch) crossover masks, the two gametes bit-interleaved, out
   const uint32_t *thrA;  // [(nwh+16)*64] 32-bit thresholds of markers [0, half), zero padded
   const uint32_t *thrB;  // [(nwh+16)*64] 32-bit thresholds of markers [half, M), zero padded
   const uint32_t *ctrB;  // [(nwh+16)*64] second Threefry counter of pair j: j + half, or 0 where that is >= M
@@ -82,6 +82,15 @@ __device__ __forceinline__ int norm_index(int i, int n) {
   // JAX retrieval indexing: negative wraps once, then clamp
   if (i < 0) i += n;
   return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// 16 bits -> 32 bits with a zero after every bit
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
 }
 
 __device__ __forceinline__ uint64_t prefix_xor64(uint64_t x) {
@@ -293,14 +302,13 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
       carry0 ^= __popcll(par0) & 1u;
       carry1 ^= __popcll(par1) & 1u;
       if (w < p.nw) {
-        // bytes x0.b0 x1.b0 x0.b1 x1.b1 ... so that markers 8v..8v+7 are one u16 at Z + 2v
-        const uint32_t a0 = (uint32_t)x0, a1 = (uint32_t)(x0 >> 32);
-        const uint32_t b0 = (uint32_t)x1, b1 = (uint32_t)(x1 >> 32);
+        // bit-interleaved: marker m's gamete-0 bit at bit 2 (m % 8), its gamete-1 bit next to it, so
+        // that markers 8v..8v+7 are one u16 at Z + 2v whose bit i belongs to byte i of genotype vector v
         uint4 z;
-        z.x = __builtin_amdgcn_perm(b0, a0, 0x05010400u);
-        z.y = __builtin_amdgcn_perm(b0, a0, 0x07030602u);
-        z.z = __builtin_amdgcn_perm(b1, a1, 0x05010400u);
-        z.w = __builtin_amdgcn_perm(b1, a1, 0x07030602u);
+        z.x = spread16((uint32_t)x0 & 0xffffu) | (spread16((uint32_t)x1 & 0xffffu) << 1);
+        z.y = spread16((uint32_t)x0 >> 16) | (spread16((uint32_t)x1 >> 16) << 1);
+        z.z = spread16((uint32_t)(x0 >> 32) & 0xffffu) | (spread16((uint32_t)(x1 >> 32) & 0xffffu) << 1);
+        z.w = spread16((uint32_t)(x0 >> 48)) | (spread16((uint32_t)(x1 >> 48)) << 1);
         *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
       }
     }
@@ -317,12 +325,11 @@ __device__ __forceinline__ uint32_t orderable(float f) {
 
 // offspring dword k of one 16-byte vector: dword k holds markers 2k, 2k+1 as bytes
 // [m0 a0, m0 a1, m1 a0, m1 a1]; output byte (marker, p) = parent p's byte (marker, mask_p).
-// zz = the vector's 16 mask bits (low byte gamete 0, high byte gamete 1).  nibble =
-// [g0(2k) g0(2k+1) g1(2k) g1(2k+1)]; the multiply drops its bits onto bit 0 of selector bytes
-// 0, 2, 1, 3 of a v_perm_b32 whose sources are {parent 1 dword, parent 0 dword}.
+// zz = the vector's 16 mask bits, bit i for output byte i.  The multiply drops bits 4k .. 4k+3 onto
+// bit 0 of the selector bytes of a v_perm_b32 whose sources are {parent 1 dword, parent 0 dword}.
 __device__ __forceinline__ uint32_t select_dword(uint32_t zz, int k, uint32_t aw, uint32_t bw) {
-  const uint32_t nib = ((zz >> (2 * k)) & 3u) | (((zz >> (8 + 2 * k)) & 3u) << 2);
-  return __builtin_amdgcn_perm(bw, aw, ((nib * 0x00208041u) & 0x01010101u) | 0x06020400u);
+  const uint32_t nib = (zz >> (4 * k)) & 0xfu;
+  return __builtin_amdgcn_perm(bw, aw, ((nib * 0x00204081u) & 0x01010101u) | 0x06020400u);
 }
 
 // the eight dosages (0, 1, 2) of one offspring vector as doubles: dosage of markers (2k, 2k+1) =

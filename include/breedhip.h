@@ -147,8 +147,9 @@ int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int
 /* ---- bit-plane storage behind the byte-layout API ------------
  * The observation format of the reference stays what it is -- (rows, M, 2) one byte per allele
  * (vec_env.py:57-62) -- but a population a VecBreedGym keeps between steps can live packed, 1 bit
- * per allele: a packed row is uint16 P[bh_packed_pitch() / 2]; P[v] holds markers 8v .. 8v+7, low
- * byte = allele-0 bits, high byte = allele-1 bits (bit t = marker 8v + t), zero beyond M.
+ * per allele: a packed row is uint16 P[bh_packed_pitch() / 2]; bit i of P[v] is byte i of the 16-byte
+ * vector v of the byte-layout row (markers 8v .. 8v+7: even bits allele 0, odd bits allele 1; i.e.
+ * numpy packbits(row_bytes, bitorder="little")), zero beyond M.
  * A step then reads M/2 bytes of parents per cross instead of 4M, and still hands out the same
  * byte-layout offspring when asked to. */
 int64_t bh_packed_pitch(const bh_ctx *ctx);

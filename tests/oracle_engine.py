@@ -58,19 +58,15 @@ class OracleEngine(EngineBase):
             gebv.reshape(-1, self.n_traits)[: len(i)] = torch.from_numpy(co.gebv(self._g(out[: len(i)]), self.effects))
 
     # ---- bit-plane rows (layout documented in include/breedhip.h) ------------------------------
-    def _pack_np(self, g):  # (rows, M, 2) u8 -> (rows, packed_pitch) u8
+    def _pack_np(self, g):  # (rows, M, 2) u8 -> (rows, packed_pitch) u8: bit i of the row = allele byte i
         rows, M = g.shape[0], self.n_markers
-        nw = (M + 63) // 64
-        bits = np.zeros((rows, nw * 64, 2), np.uint8)
-        bits[:, :M] = g & 1
-        by = np.packbits(bits.reshape(rows, nw * 8, 8, 2), axis=2, bitorder="little")[:, :, 0, :]
-        return np.ascontiguousarray(by).reshape(rows, nw * 16)  # (allele-0 byte, allele-1 byte) per 8 markers
+        by = np.zeros((rows, self.packed_pitch * 8), np.uint8)
+        by[:, : 2 * M] = g.reshape(rows, 2 * M) & 1
+        return np.packbits(by, axis=1, bitorder="little")
 
     def _unpack_np(self, p):  # (rows, packed_pitch) u8 -> (rows, M, 2) u8
-        rows = p.shape[0]
-        by = p.reshape(rows, -1, 1, 2)
-        bits = np.unpackbits(by, axis=2, count=8, bitorder="little")  # (rows, nvp, 8, 2)
-        return np.ascontiguousarray(bits.reshape(rows, -1, 2)[:, : self.n_markers])
+        bits = np.unpackbits(np.ascontiguousarray(p), axis=1, bitorder="little")
+        return np.ascontiguousarray(bits[:, : 2 * self.n_markers].reshape(p.shape[0], self.n_markers, 2))
 
     def _put_bytes(self, out, g):
         out[: g.shape[0]] = 0

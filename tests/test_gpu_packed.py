@@ -25,13 +25,13 @@ def gebv_close(got, ref64):
 
 
 def pack_numpy(g):
-    """(rows, M, 2) 0/1 -> (rows, 8 * nw) uint16 in the documented layout (include/breedhip.h)."""
+    """(rows, M, 2) 0/1 -> (rows, 8 * nw) uint16 in the documented layout (include/breedhip.h): bit i of
+    word v = byte i of the 16-byte vector v of the byte-layout row."""
     rows, M, _ = g.shape
     nw = (M + 63) // 64
-    bits = np.zeros((rows, nw * 64, 2), np.uint8)
-    bits[:, :M] = g
-    by = np.packbits(bits.reshape(rows, nw * 8, 8, 2), axis=2, bitorder="little")[:, :, 0, :]  # (rows, nvp, 2)
-    return by[..., 0].astype(np.uint16) | (by[..., 1].astype(np.uint16) << 8)
+    by = np.zeros((rows, nw * 64 * 2), np.uint8)
+    by[:, : 2 * M] = g.reshape(rows, 2 * M)
+    return np.packbits(by, axis=1, bitorder="little").view(np.uint16)
 
 
 def packed_host(t):
