@@ -311,6 +311,8 @@ int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 
 bh::RowParams base_params(const bh_ctx *c) {
   bh::RowParams p{};
   p.eff = c->d_eff;
+  p.dig = c->d_dig16;
+  p.scale = c->d_scale;
   p.pitch = c->pitch;
   p.effPitch = c->effPitch;
   p.zpitch = (int64_t)16 * c->nw;

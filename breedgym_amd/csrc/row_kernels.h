@@ -59,6 +59,8 @@ struct RowParams {
   float *gebv;         // (rows, T) or null
   const uint8_t *Z;    // cross: (B, zpitch) masks from mask_kernel
   const double *eff;   // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
+  const uint4 *dig;    // (T, nvec, 3) int16 digit planes of the fixed-point effects (row_role_pipelined)
+  const double *scale; // (T) 2^-s_t
   int64_t pitch;       // bytes per genotype row (multiple of 16)
   int64_t effPitch;    // doubles per trait (= 8 * nvec)
   int64_t zpitch;
@@ -551,11 +553,16 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
   }
   // no s_setprio: next to four-wave mask groups, see row_role
 
-  double acc[R][TT];
+  // GEBV in exact fixed point (see packed_stream_role in packed_kernels.h): three balanced base-65536
+  // digits of round(e * 2^s_t), dosage pairs as the int16 halves of (w + (w >> 8)) & 0x00FF00FF, one
+  // v_dot2_i32_i16 per pair and digit instead of conversions and f64 FMAs
+  int acc[R][TT][3];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) acc[r][t] = 0.0;
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[r][t][j] = 0;
 
   const int last = p.nvec - 1;
   struct Vecs {
@@ -576,14 +583,13 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
     const int v = base + lane;
     const bool has = v < p.nvec;
     const int vv = v < last ? v : last;
-    double2 ef[TT][4];
+    uint4 dg[TT][3];
 #pragma unroll
     for (int q = 0; q < TT; ++q) {
-      const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)q * p.effPitch + 8 * (int64_t)vv);
-      ef[q][0] = ep[0];
-      ef[q][1] = ep[1];
-      ef[q][2] = ep[2];
-      ef[q][3] = ep[3];
+      const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
+      dg[q][0] = dp[0];
+      dg[q][1] = dp[1];
+      dg[q][2] = dp[2];
     }
     load_vecs(base + 64, next);
     uint4 oo[R];
@@ -598,15 +604,24 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
       oo[r] = o;
     }
     if (has) {  // a lane that redid the last vector must not count it twice
+      typedef short short2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int q = 0; q < TT; ++q) {
-        const double e[8] = {ef[q][0].x, ef[q][0].y, ef[q][1].x, ef[q][1].y, ef[q][2].x, ef[q][2].y, ef[q][3].x, ef[q][3].y};
+      for (int r = 0; r < R; ++r) {
+        const uint32_t w[4] = {oo[r].x, oo[r].y, oo[r].z, oo[r].w};
+        uint32_t pr[4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const Dosage8 d = dosages(oo[r]);
+        for (int k = 0; k < 4; ++k) pr[k] = (w[k] + (w[k] >> 8)) & 0x00FF00FFu;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) acc[r][q] = fma(d.d[k], e[k], acc[r][q]);
-        }
+        for (int q = 0; q < TT; ++q)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const uint32_t dd[4] = {dg[q][j].x, dg[q][j].y, dg[q][j].z, dg[q][j].w};
+            int a = acc[r][q][j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
+            acc[r][q][j] = a;
+          }
       }
     }
   };
@@ -624,19 +639,11 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-      double s = acc[r][t];
+      long long s = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      acc[r][t] = s;
+      if (lane == 0 && live[r]) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)((double)s * p.scale[p.t0 + t]);
     }
-  if (lane == 0) {
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (live[r]) {
-#pragma unroll
-        for (int t = 0; t < TT; ++t) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
-      }
-  }
 }
 
 template <int WAVES>
