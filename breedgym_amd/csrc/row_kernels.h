@@ -175,6 +175,10 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   const int tid = wv * 64 + lane;
   const int c = __builtin_amdgcn_readfirstlane(block * GROUPS + grp);
   if (c >= p.n_rows) return;  // only possible for WAVES == 1, whose waves never meet at a barrier
+  // four-wave groups run next to row waves at the default priority (few keyed crosses, the launch
+  // is bound by the streaming): one step above them the mask role is out of the way sooner --
+  // 1-5 % on most shapes, 11 % at 2200 x 16k markers, -2 % on one (profiles/r01_ab_mask_priority.txt)
+  if constexpr (SYNC == SYNC_COUNTER) __builtin_amdgcn_s_setprio(1);
   uint64_t *S = reinterpret_cast<uint64_t *>(lds_raw + (size_t)grp * p.group_lds);  // [nwh + 1][4]
 
   // ---- gamete keys: keys = split(sim_key, nkeys); gamete (c, q) owns keys[1 + 2c + q] (double
