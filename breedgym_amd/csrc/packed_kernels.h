@@ -222,7 +222,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   // digits (as gebv_mfma.h cuts them into six base-256 ones), the dosages of a marker pair are the
   // two int16 halves of (w + (w >> 8)) & 0x00FF00FF, and a v_dot2_i32_i16 per pair and digit replaces
   // eight conversions and eight f64 FMAs per vector.  |digit| <= 2^15 and dosage <= 2, so a lane's
-  // int32 sums stay below 2^31 for rows of up to 2^17 markers.
+  // int32 sums stay below 2^31 for rows of up to 2^21 markers (bh_max_markers() is 2^18).
   int acc[R][TT][3];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -368,9 +368,9 @@ template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   const int wave = (int)(threadIdx.x >> 6);
   if constexpr (TT == 1 || TT == 2) {
-    // packed rows out, GEBV wanted, rows of up to 16384 markers (reset's founder gather, a cross
-    // without run-ahead): the pipelined stream
-    if (p.outp && p.zpitch <= 4096) {
+    // packed rows out, GEBV wanted (reset's founder gather, a cross without run-ahead): the
+    // pipelined stream
+    if (p.outp) {
       if (p.outb)
         packed_stream_role<TT, MODE, R, true>(p, (int)blockIdx.x, wave);
       else
@@ -404,13 +404,11 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     if ((int)blockIdx.x < rp.n_blocks) {
 #if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr ((TT == 1 || TT == 2) && MW == 4) {
-        if (rp.zpitch <= 4096) {  // rows of up to 16384 markers; longer ones gain nothing from it
-          if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true>(rp, (int)blockIdx.x, wave);
-          else
-            packed_stream_role<TT, MODE_CROSS, R, false>(rp, (int)blockIdx.x, wave);
-          return;
-        }
+        if (rp.outb)
+          packed_stream_role<TT, MODE_CROSS, R, true>(rp, (int)blockIdx.x, wave);
+        else
+          packed_stream_role<TT, MODE_CROSS, R, false>(rp, (int)blockIdx.x, wave);
+        return;
       }
 #endif
       packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave);
