@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- crosses/s through vector env.step() on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode envs|population]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (N = 1): BASELINE.json configs[1] -- a 370-individual x 10k-marker synthetic germplasm,
-16 envs x 256 individuals = 4096 crosses per generation, GEBV reward every step, episodes of 10
-generations with autoreset (so every 10th step also pays a reset, as in the reference's
-scripts/time_vec.py:57-65 protocol).  A "step" is one ``VecBreedGym.step``: fused parent
-gather + meiosis + offspring write + GEBV, the reward reduction, and the reset when due.
-Inputs (germplasm, genetic map, actions) are resident in HBM before the timed region; outputs
-stay on the device (``sync_rewards=False``), nothing is copied to the host inside it.
+Workload (N = 1, default mode): BASELINE.json configs[1] -- a 370-individual x 10k-marker synthetic
+germplasm, 16 envs x 256 individuals = 4096 crosses per generation, GEBV reward every step, episodes
+of 10 generations with autoreset (so every 10th step also pays a reset, as in the reference's
+scripts/time_vec.py:57-65 protocol).  A "step" is one ``VecBreedGym.step``: fused parent gather +
+meiosis + offspring write + GEBV + reward, and the reset when due.  Inputs (germplasm, genetic map,
+actions) are resident in HBM before the timed region; outputs stay on the device
+(``sync_rewards=False``), nothing is copied to the host inside it.
 
-N > 1: one process per GPU, every rank steps its own 16 envs (env-sharded): there
-is no data-path collective, so scaling is "weak"; value = all ranks' crosses / max rank time.
+N > 1, ``--mode envs`` (default): one process per GPU, every rank steps its own 16 envs (env-sharded,
+SURVEY.md 8e): no data-path collective, "weak" scaling; value = all ranks' crosses / max rank time.
+``--mode population``: BASELINE configs[3] -- one population of N x 8192 individuals x 100k markers
+sharded row-wise over the ranks; a step is one generation of ``ShardedPopulation.select_and_cross``
+(local GEBV -> local top-k -> RCCL all-gather of candidates -> global top-k -> RCCL all-gather of the
+winners' bit-plane rows -> every rank crosses its shard); weak scaling as well (8192 per rank).
+
+The JSON line also carries, at N = 1: ``roofline`` (dominant kernel of the headline: bytes it must
+move for the storage in use / its HIP-event time / 8 TB/s), ``configs`` (configs[2] and configs[4]
+timed the same way), ``cpu_baseline`` (the C oracle on the host's cores).
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +39,24 @@ sys.path.insert(0, str(ROOT))
 
 N_GERMPLASM, N_MARKERS, N_ENVS, N_PER_ENV, N_GENERATIONS = 370, 10_000, 16, 256, 10
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def packed_pitch(M):
+    return 16 * ((M + 63) // 64)
+
+
+def cross_bytes(M, C, B, storage, observations):
+    """Bytes one cross launch must move for the layout in use:
+    bits  : per cross two bit-plane parents read (2 x M/4), the bit-plane offspring written (M/4), the
+            byte-layout observation written when eager (2M); per keyed cross (B of them: n with shared
+            keys) one mask row read and the next generation's written (M/4 each);
+    bytes : per cross two byte-layout parents read (2 x 2M) and the offspring written (2M), + masks.
+    Shared, cache-resident tables (thresholds, effect digits) are not counted."""
+    pp = packed_pitch(M)
+    masks = 2 * B * pp
+    if storage == "bits":
+        return C * (3 * pp + (2 * M if observations == "eager" else 0)) + masks
+    return C * 6 * M + masks
 
 
 def cpu_baseline(gm, geno, rng_mode, seconds_hint=8.0):
@@ -83,6 +109,7 @@ def cpu_baseline(gm, geno, rng_mode, seconds_hint=8.0):
 
 
 def time_steps(env, actions, steps, warmup, barrier):
+    """-> (seconds for `steps` steps incl. the final sync, seconds the host needed to issue them)."""
     import torch
 
     for i in range(warmup):
@@ -91,15 +118,34 @@ def time_steps(env, actions, steps, warmup, barrier):
     t0 = time.perf_counter()
     for i in range(steps):
         env.step(actions[i % len(actions)])
+    t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
-    return dt
+    return dt, t_issue
+
+
+def time_events(launch, reps, warm=5):
+    """HIP events on the stream the launches go to (torch's current stream = the engine's), around
+    `reps` back-to-back calls of `launch(i)`; -> ms per call."""
+    import torch
+
+    for i in range(warm):
+        launch(i)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for i in range(reps):
+        launch(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
 
 
 def time_cross_launches(env, actions, reps):
-    """HIP events around `reps` back-to-back launches of the hot-path kernel alone (the fused two-role
-    launch: streams this generation, makes the next one's masks), in the env's own storage layout."""
+    """The hot-path launch alone (the fused two-role launch: streams this generation, makes the next
+    one's masks), in the env's own storage layout, through the same C entry point the env uses but
+    without the reward reduction and the reset."""
     import torch
 
     eng = env.simulator.engine
@@ -118,16 +164,148 @@ def time_cross_launches(env, actions, reps):
         def launch(i):
             eng.cross(pool, E, n, actions[i % len(actions)], n, key, env._rng_mode, out, gebv)
 
-    for i in range(5):
-        launch(i)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    return time_events(launch, reps)
+
+
+def roofline_of(kernel, nbytes, ms, **extra):
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "bytes_per_launch": nbytes, "kernel_ms": ms, **extra}
+
+
+def committed_traffic(kernel_prefix):
+    """PMC traffic (2 x FETCH_SIZE + WRITE_SIZE, per launch) from the committed rocprofv3 passes under
+    profiles/: a measurement of an earlier run of the same command, NOT of this run; the source is named."""
+    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        f = ROOT / "profiles" / name
+        if not f.exists():
+            continue
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        entries = d.get("kernels", [d])
+        for e in entries:
+            if str(e.get("kernel", "")).replace(" ", "").startswith(kernel_prefix.replace(" ", "")):
+                return e.get("hbm_bytes_per_launch"), f"profiles/{name} (rocprofv3 --pmc passes of an earlier run; not measured by this run)"
+    return None, "none: no committed PMC pass for this kernel"
+
+
+def bench_c3(steps, warmup, barrier):
+    """BASELINE configs[2]: 2048 x 100k germplasm, 4 envs x 2048 = 8192 crosses per step, defaults."""
+    import torch
+
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N, M, E, n = 2048, 100_000, 4, 2048
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=1, seed=1)
+    geno = synthetic_genotypes(N, M, seed=0)
+    out = {"workload": "BASELINE configs[2]: 2048 x 100k germplasm, 4 envs x 2048 = 8192 crosses/gen, GEBV reward "
+                       "every step, 10-generation episodes with autoreset, shared keys, bit-plane state"}
+    arng = np.random.default_rng(3)
+    for name, obs in (("eager", "eager"), ("lazy_observations", "lazy")):
+        env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, num_generations=N_GENERATIONS,
+                          autoreset=True, reward_shaping=True, sync_rewards=False, genetic_map=gm, observations=obs)
+        actions = [torch.from_numpy(arng.integers(0, n, (E, n, 2), dtype=np.int32)).to(env.device) for _ in range(4)]
+        env.reset(seed=7)
+        dt, _ = time_steps(env, actions, steps, warmup, barrier)
+        kms = time_cross_launches(env, actions, max(10, steps))
+        nbytes = cross_bytes(M, E * n, n, "bits", obs)
+        r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
+             "roofline": roofline_of("packed_cross_kernel<1,4,2>", nbytes, kms,
+                                     api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
+             "step_frac_of_hbm_peak": nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
+        if name == "eager":
+            out.update(r)
+        else:
+            out[name] = r
+        del env
+    return out
+
+
+def bench_c5(reps):
+    """BASELINE configs[4]: GEBV of 2048 individuals x 100k markers x 8 traits (int8 digits on the matrix cores)."""
+    import torch
+
+    from breedgym_amd import HipEngine
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N, M, T = 2048, 100_000, 8
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=T, seed=1)
+    geno = synthetic_genotypes(N, M, seed=0)
+    eng = HipEngine(gm.recombination_vec, gm.marker_effects)
+    rows = eng.upload_population(geno)
+    packed = eng.pack(rows)
+    g = eng.empty((N, T), torch.float32)
+    ms_bytes = time_events(lambda i: eng.gebv(rows, g), reps)
+    ms_bits = time_events(lambda i: eng.gather_packed(packed, None, N, None, None, g), reps)
+    eff_bytes = M * 64  # the int8 digit pack, read once per row tile from L2
+    return {
+        "workload": "BASELINE configs[4]: GEBV of 2048 x 100k markers x 8 traits, exact int8-digit products on MFMA",
+        "byte_rows": {"ms": ms_bytes, "individuals_per_s": N / (ms_bytes * 1e-3),
+                      "roofline": roofline_of("gebv (bh_gebv, byte-layout rows)", N * 2 * M + eff_bytes, ms_bytes)},
+        "bit_planes": {"ms": ms_bits, "individuals_per_s": N / (ms_bits * 1e-3),
+                       "roofline": roofline_of("gebv (bh_gather_packed, bit-plane rows)", N * packed_pitch(M) + eff_bytes, ms_bits),
+                       "api_level_GBps": N * 2 * M / (ms_bits * 1e-3) / 1e9},
+    }
+
+
+def bench_population(args, rank, world, local_rank, use_dist, barrier):
+    """BASELINE configs[3]: one population sharded row-wise, 8192 x 100k per rank, k = n_total // 10."""
+    import torch
+    import torch.distributed as dist
+
+    from breedgym_amd.simulator import Simulator
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector.distributed import ShardedPopulation
+
+    n_local, M = 8192, 100_000
+    n_total = n_local * world
+    k = min(n_total // 10, 16384)
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=1, seed=1)
+    sim = Simulator(genetic_map=gm, seed=5, device=local_rank)
+    eng = sim.engine
+    base = synthetic_genotypes(512, M, seed=10 + rank)  # a rank's shard: 8192 rows drawn from 512 distinct ones
+    rows = eng.upload_population(base)
+    pick = torch.from_numpy(np.random.default_rng(rank).integers(0, 512, n_local, dtype=np.int32)).to(eng.device)
+    shard = eng.empty_population(n_local)
+    eng.gather(rows, pick, shard)
+    del rows
+    sp = ShardedPopulation(sim, shard, storage="bits")
+    del shard
+    prng = np.random.default_rng(3)
+    pairs = [torch.from_numpy(prng.integers(0, k, (n_local, 2), dtype=np.int32)).to(eng.device) for _ in range(2)]
+    key = np.array([0, 5], np.uint32)
+    for i in range(args.warmup):
+        sp.select_and_cross(k, pairs[i % 2], key)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sp.select_and_cross(k, pairs[i % 2], key)
     torch.cuda.synchronize()
-    ev0.record()
-    for i in range(reps):
-        launch(i)
-    ev1.record()
-    torch.cuda.synchronize()
-    return ev0.elapsed_time(ev1) / reps
+    dt = time.perf_counter() - t0
+    barrier()
+    t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    if rank == 0:
+        pp = packed_pitch(M)
+        line = {
+            "metric": "crosses/sec (population-sharded generation: top-k GEBV selection + crosses) at 8192 x 100k markers per GPU",
+            "value": world * args.steps * n_local / dt_max, "unit": "crosses/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[3]: {n_total} individuals x 100k markers over {world} GPU(s), 8192 per rank, "
+                            f"top-{k} by GEBV, every rank crosses its shard from the replicated winners",
+                "n_markers": M, "crosses_per_step_per_gpu": n_local, "storage": "bits",
+                "collectives": f"all-gather of {k} (score, index) candidates per rank; all-gather of the winners' "
+                               f"bit-plane rows ({k * pp / 1e6:.0f} MB in total per generation)",
+            },
+        }
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -135,10 +313,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=("envs", "population"), default="envs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the headline configuration: no CPU leg, no other key mode / storage lines (profiling runs, "
-                         "so that a kernel name in the profile is one configuration)")
+                    help="only the headline configuration: no CPU leg, no other key mode / storage / config lines "
+                         "(profiling runs, so that a kernel name in the profile is one configuration)")
+    ap.add_argument("--only", choices=("c3", "c5"), default=None,
+                    help="run only that extra configuration (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +343,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "population":
+        bench_population(args, rank, world, local_rank, use_dist, barrier)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    if args.only == "c3":
+        print(json.dumps({"configs": {"c3": bench_c3(max(10, args.steps // 10), max(3, args.warmup // 10), barrier)}}))
+        return
+    if args.only == "c5":
+        print(json.dumps({"configs": {"c5": bench_c5(max(20, args.steps // 4))}}))
+        return
+
     gm = synthetic_genetic_map(N_MARKERS, n_chr=10, n_traits=1, seed=1)
     geno = synthetic_genotypes(N_GERMPLASM, N_MARKERS, seed=0)
 
@@ -184,13 +382,8 @@ def main():
         for _ in range(16)
     ]
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     env.reset(seed=100 + rank)
-    dt = time_steps(env, actions, args.steps, args.warmup, barrier)
+    dt, t_issue = time_steps(env, actions, args.steps, args.warmup, barrier)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,11 +397,12 @@ def main():
     if not args.headline_only:
         env_i = make_env("independent")
         env_i.reset(seed=100 + rank)
-        dt_i = time_steps(env_i, actions, args.steps, args.warmup, barrier)
+        dt_i, _ = time_steps(env_i, actions, args.steps, args.warmup, barrier)
         ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(ti, op=dist.ReduceOp.MAX)
         kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
+        del env_i
 
     # The other storage / observation choices of the same env, same outputs (one GPU only: extra
     # lines, not the headline): byte-layout state, and bit planes with on-demand observations.
@@ -218,21 +412,21 @@ def main():
                          ("lazy_observations", dict(storage="bits", observations="lazy"))):
             env_v = make_env("shared", **kw)
             env_v.reset(seed=100 + rank)
-            dt_v = time_steps(env_v, actions, args.steps, args.warmup, barrier)
-            variants[name] = {"value": args.steps * N_ENVS * N_PER_ENV / dt_v, "ms_per_step": dt_v / args.steps * 1e3,
-                              "kernel_ms": time_cross_launches(env_v, actions, max(20, args.steps))}
+            dt_v, _ = time_steps(env_v, actions, args.steps, args.warmup, barrier)
+            kms = time_cross_launches(env_v, actions, max(20, args.steps))
+            nb = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, kw["storage"], kw.get("observations", "eager"))
+            # requested bytes over time, NOT an HBM fraction: at this size the parents of a generation are the
+            # previous launch's output and come out of the Infinity Cache (the byte layout asks for 246 MB)
+            variants[name] = {"value": args.steps * crosses_per_step / dt_v, "ms_per_step": dt_v / args.steps * 1e3,
+                              "kernel_ms": kms, "bytes_requested_per_launch": nb,
+                              "requested_GBps": nb / (kms * 1e-3) / 1e9}
             del env_v
 
-    # algorithmic bytes per launch: 2 parents x 2M read + 2M written per cross
-    alg_bytes = 6 * N_MARKERS * crosses_per_step
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if pmc.exists():
-        try:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # bytes the headline launch must move in the layout the env uses (bit planes + eager observation):
+    # 2.75 M per cross + the mask rows; the reference-layout figure of SURVEY 8d (6 M per cross: two
+    # 2M-byte parents read, 2M written) is reported beside it as what an API-level observer would count.
+    nbytes = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, "bits", "eager")
+    traffic, traffic_source = committed_traffic("packed_cross_kernel<1,4")
 
     if rank == 0:
         line = {
@@ -256,14 +450,19 @@ def main():
                 "storage": "bits (default): 1 bit per allele between steps, byte-layout observation written every step",
                 "sharding": "envs across ranks, no data-path collective",
             },
-            "roofline": {
-                "kernel": "packed_cross_kernel<TT=1,MW=4,R=2> (row role: bit-plane parents -> select -> byte-layout "
-                          "observation + bit-plane state + GEBV, 2 rows per wave; mask role: next generation's Threefry)",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
-                "kernel_crosses_per_s": crosses_per_step / (kern_ms * 1e-3),
-            },
+            "roofline": roofline_of(
+                "packed_cross_kernel<TT=1,MW=4,R=2> (row role: bit-plane parents -> select -> byte-layout observation + "
+                "bit-plane state + GEBV + reward; mask role: next generation's Threefry)",
+                nbytes, kern_ms, traffic=traffic, traffic_source=traffic_source,
+                bytes_model="per cross: 2 x M/4 parents read + M/4 state written + 2M observation written; per keyed "
+                            "cross: M/4 mask row read + M/4 written for the next generation",
+                api_level_GBps=6 * N_MARKERS * crosses_per_step / (kern_ms * 1e-3) / 1e9,
+                api_level_note="SURVEY 8d's reference-layout count (6M per cross) over the same time: what the byte layout "
+                               "would have had to move; not a roofline fraction of this kernel",
+                kernel_crosses_per_s=crosses_per_step / (kern_ms * 1e-3),
+                step_frac_of_hbm_peak=nbytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBPS,
+            ),
+            "host_issue_ms_per_step": t_issue / args.steps * 1e3,
         }
         if ti is not None:
             line["independent_rng"] = {
@@ -271,13 +470,17 @@ def main():
                 "value": world * args.steps * crosses_per_step / float(ti.item()),
                 "ms_per_step": float(ti.item()) / args.steps * 1e3,
                 "kernel_ms": kern_ms_i,
-                "achieved_GBps": alg_bytes / (kern_ms_i * 1e-3) / 1e9,
             }
         if variants:
             variants["byte_layout_storage"]["note"] = "storage='bytes': the byte layout is the state; cross_kernel<1,4,2>"
             variants["lazy_observations"]["note"] = ("storage='bits', observations='lazy': the step hands out a handle "
                                                       "that expands to the byte layout on demand")
             line.update(variants)
+        if world == 1 and not args.headline_only:
+            del env
+            torch.cuda.empty_cache()
+            line["configs"] = {"c3": bench_c3(max(10, args.steps // 10), max(3, args.warmup // 10), barrier),
+                               "c5": bench_c5(max(20, args.steps // 4))}
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline(gm, geno, 0)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

@@ -546,13 +546,20 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
     std::vector<double> scale((size_t)n_traits);
     std::vector<int> shift((size_t)n_traits);
     for (int64_t t = 0; t < n_traits; ++t) {
-      double emax = 0.0;
-      for (int64_t m = 0; m < n_markers; ++m) emax = std::max(emax, std::fabs((double)effects[m * n_traits + t]));
+      double emax = 0.0, esum = 0.0;
+      for (int64_t m = 0; m < n_markers; ++m) {
+        const double a = std::fabs((double)effects[m * n_traits + t]);
+        emax = std::max(emax, a);
+        esum += a;
+      }
       int sft = 0;
-      if (emax > 0.0 && std::isfinite(emax)) {
-        int e2;
-        std::frexp(emax, &e2);  // emax = f * 2^e2, f in [0.5, 1)
-        sft = 46 - e2;          // emax * 2^sft < 2^46
+      if (emax > 0.0 && std::isfinite(esum)) {
+        int e2, s2;
+        std::frexp(emax, &e2);        // emax = f * 2^e2, f in [0.5, 1)
+        std::frexp(2.0 * esum, &s2);  // the largest |GEBV| any genotype can reach: dosage <= 2
+        // every fixed-point effect fits the digits (|.| < 2^46), and the int64 in which the digit sums
+        // are recombined holds any row: sum_m 2 |round(e_m 2^sft)| <= 2 esum 2^sft + M < 2^61 + 2^18
+        sft = std::min(46 - e2, 61 - s2);
       }
       shift[(size_t)t] = sft;
       scale[(size_t)t] = std::ldexp(1.0, -sft);

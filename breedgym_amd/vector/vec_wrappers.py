@@ -120,7 +120,11 @@ class PairScores(VectorWrapper):
         s = _as_device_f32(actions, eng).reshape(self.num_envs, n * n)
         best = eng.topk(s, n).to(torch.int64)  # (E, n) flat indices, best first
         vals = torch.gather(s, 1, best)
-        per_cross = torch.ceil(torch.softmax(vals, dim=1) * n).to(torch.int64)  # offspring per pair
+        # jax.nn.softmax in f32, spelled out so that the one order-dependent step -- the sum -- is done
+        # in f64 and rounded once: ceil() makes the offspring counts sensitive to the last bit
+        ex = torch.exp(vals - vals.max(dim=1, keepdim=True).values)
+        sm = ex / ex.sum(dim=1, keepdim=True, dtype=torch.float64).to(torch.float32)
+        per_cross = torch.ceil(sm * n).to(torch.int64)  # offspring per pair
         pairs = torch.stack((torch.div(best, n, rounding_mode="floor"), best % n), dim=2)
         # jnp.repeat(pairs, per_cross, total_repeat_length=n): slot s takes the first pair whose
         # cumulative count exceeds s

@@ -1,0 +1,338 @@
+"""GPU: the BASELINE.json configurations at their real shapes on the path the product uses, and the
+single-env / wrapper surface on the device, against the oracle.
+
+* configs[1] (c2): the headline env -- 16 envs x 256 individuals of a 370 x 10k germplasm, all defaults
+  (shared keys, bit-plane state, byte observation) -- stepped through a whole episode and over the
+  autoreset, byte for byte equal to the oracle chain ``founders -> cross -> cross ...``
+  (the reference's tests/test_vec.py:115-133 loop with the oracle in place of the chromax constants);
+* configs[2] (c3): 2048 x 100k germplasm, 4 envs x 2048 = 8192 crosses, default path, two generations
+  (the second one reads run-ahead masks), every cross against the oracle;
+* configs[4] (c5): GEBV of 2048 x 100k x 8 traits against the f64 oracle, byte rows and bit planes;
+* long rows with same-sign effects (the fixed-point recombination must not wrap);
+* ``BreedGym``, ``SimplifiedBreedGym``, ``KBestBreedGym``, ``PairScores``, ``WheatBreedGym`` on the
+  device against the same classes driven by the oracle-backed engine (tests/oracle_engine.py):
+  reference tests/test_env.py:103-119, tests/test_wrappers.py:7-88, tests/test_vec.py:186-204.
+"""
+import numpy as np
+import pytest
+import torch
+from oracle_engine import OracleEngine
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+GEBV_RTOL = 1e-5  # BASELINE.json north_star: "within 1e-5 on GEBV"
+
+
+def gebv_close(got, ref64):
+    scale = np.maximum(np.abs(ref64), 1.0)
+    return bool(np.all(np.abs(np.asarray(got, np.float64) - ref64) <= GEBV_RTOL * scale))
+
+
+def u8(x):
+    return np.asarray(x).view(np.uint8)
+
+
+# ---- configs[1]: the headline env ---------------------------------------------------------------------
+
+
+def test_c2_headline_env_equals_oracle_chain():
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N, M, E, n, G = 370, 10_000, 16, 256, 10
+    gm = synthetic_genetic_map(M, n_chr=10, n_traits=1, seed=1)
+    geno = synthetic_genotypes(N, M, seed=0)
+    env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, num_generations=G,
+                      reward_shaping=True, genetic_map=gm)  # every other keyword at its default
+    assert env.storage == "bits" and env.observations == "eager"
+    pop, info = env.reset(seed=100)
+    f, env_key = co.founders(co.key_from_seed(100), E, N, n)
+    ref = geno.view(np.uint8)[f]
+    assert np.array_equal(u8(pop), ref)
+    assert gebv_close(np.asarray(info["GEBV"]), co.gebv(ref, gm.marker_effects, want64=True)[1])
+    sim_key = co.key_from_seed(100)
+    arng = np.random.default_rng(2)
+    for step in range(G + 3):  # a whole episode, the autoreset, and three steps of the next one
+        a = arng.integers(0, n, (E, n, 2), dtype=np.int32)
+        pop, rews, ter, tru, info = env.step(a)
+        ref, sim_key = co.cross(ref, a, gm.recombination_vec, sim_key, 0)
+        g64 = co.gebv(ref, gm.marker_effects, want64=True)[1]
+        assert gebv_close(np.asarray(info["GEBV"]), g64), f"step {step}"
+        assert np.allclose(rews, g64.max(axis=(1, 2)), rtol=GEBV_RTOL)
+        assert np.array_equal(env.simulator.random_key, sim_key)
+        if step == G - 1:  # horizon: the observation is the next episode's founders (vec_env.py:102-107)
+            assert tru.all() and env.step_idx == 0
+            f, env_key = co.founders(env_key, E, N, n)
+            ref = geno.view(np.uint8)[f]
+        else:
+            assert not tru.any()
+        assert np.array_equal(u8(pop), ref), f"step {step}: offspring differ from the oracle chain"
+        assert np.array_equal(env.random_key, env_key)
+        # the bit-plane state behind the observation says the same
+        assert np.array_equal(u8(env.simulator.engine.as_genotypes(env.simulator.engine.unpack(env._prows), E, n)), ref)
+
+
+# ---- configs[2]: wheat scale on the default path ------------------------------------------------------
+
+
+@pytest.mark.parametrize("observations", ["eager", "lazy"])
+def test_c3_default_path_full_shape(observations):
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N, M, E, n = 2048, 100_000, 4, 2048
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=1, seed=1)
+    geno = synthetic_genotypes(N, M, seed=0)
+    env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, num_generations=10,
+                      reward_shaping=True, genetic_map=gm, observations=observations)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    pop, info = env.reset(seed=3)
+    f, _ = co.founders(co.key_from_seed(3), E, N, n)
+    ref = geno.view(np.uint8)[f]
+    del geno
+    assert np.array_equal(u8(pop), ref)
+    assert gebv_close(np.asarray(info["GEBV"]), co.gebv(ref, gm.marker_effects, want64=True)[1])
+    key = co.key_from_seed(3)
+    arng = np.random.default_rng(5)
+    for gen in range(2):  # generation 1 reads the masks generation 0's launch made ahead
+        a = arng.integers(0, n, (E, n, 2), dtype=np.int32)
+        pop, rews, _, _, info = env.step(a)
+        ref, key = co.cross(ref, a, gm.recombination_vec, key, 0)
+        assert np.array_equal(env.simulator.random_key, key)
+        got = u8(pop)
+        assert got.shape == ref.shape
+        for e in range(E):  # env by env: keeps the temporaries of the comparison small
+            assert np.array_equal(got[e], ref[e]), f"generation {gen}, env {e}: offspring differ from the oracle"
+        del got
+        g64 = co.gebv(ref, gm.marker_effects, want64=True)[1]
+        assert gebv_close(np.asarray(info["GEBV"]), g64)
+        assert np.allclose(rews, g64.max(axis=(1, 2)), rtol=GEBV_RTOL)
+
+
+# ---- configs[4]: eight traits at 100k markers ----------------------------------------------------------
+
+
+def test_c5_multi_trait_gebv_full_shape():
+    from breedgym_amd import HipEngine
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N, M, T = 2048, 100_000, 8
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=T, seed=1)
+    geno = synthetic_genotypes(N, M, seed=0).view(np.uint8)
+    eng = HipEngine(gm.recombination_vec, gm.marker_effects)
+    rows = eng.upload_population(geno)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    g64 = co.gebv(geno, gm.marker_effects, want64=True)[1]
+    assert gebv_close(eng.gebv(rows).cpu().numpy(), g64)  # bh_gebv, byte-layout rows
+    packed = eng.pack(rows)
+    g = eng.empty((N, T), torch.float32)
+    eng.gather_packed(packed, None, N, None, None, g)  # GEBV straight from the bit planes
+    assert gebv_close(g.cpu().numpy(), g64)
+    # and through an index (the reset gather), a ragged row count
+    idx = torch.from_numpy(np.random.default_rng(0).integers(0, N, 777, dtype=np.int32)).to(eng.device)
+    g2 = eng.empty((777, T), torch.float32)
+    outp = eng.empty_packed(777)
+    eng.gather_packed(packed, idx, 777, outp, None, g2)
+    assert gebv_close(g2.cpu().numpy(), g64[idx.cpu().numpy()])
+    assert torch.equal(outp, packed[idx.long()])
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 8])
+@pytest.mark.parametrize("M", [131_072, 200_001])
+def test_same_sign_effects_on_long_rows_do_not_wrap(T, M):
+    """Every fixed-point route recombines digit sums in int64: sum_m dosage * round(e * 2^s) must stay
+    below 2^63 for ANY genotype.  All-ones genotypes x constant positive effects is the extreme row."""
+    from breedgym_amd import HipEngine
+
+    rows_n = 70
+    eff = np.full((M, T), 0.9, np.float32)
+    eff[:, T - 1] = -475.0  # and the extreme negative row, at the heavy-tail magnitude of the Yield column
+    r = np.full(M, 1e-4, np.float32)
+    eng = HipEngine(r, eff)
+    pop = np.ones((rows_n, M, 2), np.uint8)
+    pop[1::2, ::3, 1] = 0
+    rows = eng.upload_population(pop)
+    g64 = co.gebv(pop, eff, want64=True)[1]
+    assert np.abs(g64).max() > 2e5
+    assert gebv_close(eng.gebv(rows).cpu().numpy(), g64)
+    packed = eng.pack(rows)
+    g = eng.empty((rows_n, T), torch.float32)
+    outp = eng.empty_packed(rows_n)
+    eng.gather_packed(packed, None, rows_n, outp, None, g)  # the pipelined stream (digit products) for T <= 2
+    assert gebv_close(g.cpu().numpy(), g64)
+    # fused into a cross, with and without the byte observation
+    idx = torch.from_numpy(np.stack((np.arange(rows_n), np.arange(rows_n)), 1).astype(np.int32)[None]).to(eng.device)
+    for want_bytes in (True, False):
+        for rep in range(2):  # the second call takes the two-role launch's run-ahead masks
+            key = co.key_from_seed(1 + rep).copy() if rep == 0 else key
+            gc = eng.empty((rows_n, T), torch.float32)
+            ob = eng.empty_population(rows_n) if want_bytes else None
+            eng.cross_packed(packed, 1, rows_n, idx, rows_n, key, 0, outp, ob, gc)
+            # selfing an individual: homozygous sites stay, so GEBV of the offspring of all-ones rows is the row's
+            off = eng.download_population(eng.unpack(outp)).view(np.uint8)
+            assert gebv_close(gc.cpu().numpy(), co.gebv(off, eff, want64=True)[1])
+    out = eng.empty_population(rows_n)
+    gb = eng.empty((rows_n, T), torch.float32)
+    key = co.key_from_seed(9).copy()
+    for rep in range(2):
+        eng.cross(rows, 1, rows_n, idx, rows_n, key, 0, out, gb)
+        assert gebv_close(gb.cpu().numpy(), co.gebv(eng.download_population(out).view(np.uint8), eff, want64=True)[1])
+
+
+# ---- the single-env surface and the wrappers on the device, against the oracle-backed twin ------------
+
+
+M1, N1 = 1000, 60
+
+
+@pytest.fixture(scope="module")
+def small():
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    gm = synthetic_genetic_map(M1, n_chr=4, n_traits=1, seed=5)
+    geno = synthetic_genotypes(N1, M1, seed=6)
+    return gm, geno
+
+
+def twins(cls, small, gm=None, **kw):
+    """The same environment twice: on the device, and on the CPU oracle through the engine seam."""
+    gm0, geno = small
+    gm = gm or gm0
+    dev = cls(initial_population=geno, genetic_map=gm, **kw)
+    ora = cls(initial_population=geno, genetic_map=gm, engine=OracleEngine(gm.recombination_vec, gm.marker_effects), **kw)
+    assert dev.simulator.engine.device.type == "cuda" and type(dev.simulator.engine).__name__ == "HipEngine"
+    return dev, ora
+
+
+def test_breedgym_on_device_equals_oracle(small):  # reference tests/test_env.py:22-34, 103-119
+    from breedgym_amd import BreedGym
+
+    gm, geno = small
+    dev, ora = twins(BreedGym, small, reward_shaping=False)
+    for env in (dev, ora):
+        env.reset(seed=7)
+    action = np.array([[1, 2], [1, 5], [1, 7], [2, 5], [2, 9], [4, 7], [4, 8], [5, 9], [6, 8], [6, 9]])
+    ref, key = geno.view(np.uint8)[None], co.key_from_seed(7)
+    for i in range(10):
+        pd_, rd, terd, trud, infd = dev.step(action)
+        po, ro, _, truo, info = ora.step(action)
+        ref, key = co.cross(ref, action[None].astype(np.int32), gm.recombination_vec, key, 0)
+        assert np.array_equal(u8(pd_), ref[0]) and np.array_equal(u8(po), ref[0])
+        assert trud == truo == (i == 9) and not terd
+        assert gebv_close(infd["GEBV"].to_numpy(), co.gebv(ref[0], gm.marker_effects, want64=True)[1])
+        assert list(infd["GEBV"].columns) == gm.trait_names
+        assert abs(rd - ro) <= 1e-5 * max(1.0, abs(ro)) and ((rd == 0) == (i < 9))
+        assert np.array_equal(dev.simulator.random_key, key)
+    assert abs(rd - co.gebv(ref[0], gm.marker_effects, want64=True)[1].mean()) < 1e-5 * max(1.0, abs(rd))
+    # the population changes size with the action (test_num_progenies), corrcoef is cached and bounded
+    for n in (1, 5, 33):
+        dev.reset(seed=1)
+        ora.reset(seed=1)
+        a = np.random.default_rng(n).integers(0, N1, (n, 2))
+        pd_, *_ = dev.step(a)
+        po, *_ = ora.step(a)
+        assert pd_.shape == (n, M1, 2) and np.array_equal(u8(pd_), u8(po))
+        assert np.allclose(np.asarray(dev.corrcoef), np.asarray(ora.corrcoef), atol=1e-5)
+        assert dev.corrcoef is dev.corrcoef and dev.GEBV is dev.GEBV
+    # a random founder subset (reset options), then a step
+    sd, _ = dev.reset(seed=4, options={"n_individuals": 9})
+    so, _ = ora.reset(seed=4, options={"n_individuals": 9})
+    assert sd.shape == (9, M1, 2) and np.array_equal(u8(sd), u8(so))
+    assert gebv_close(dev.GEBV.to_numpy(), co.gebv(u8(so), gm.marker_effects, want64=True)[1])
+
+
+@pytest.mark.parametrize("which", ["simplified", "kbest"])
+def test_simplified_and_kbest_on_device_equal_oracle(small, which):  # reference tests/test_wrappers.py:7-88
+    from breedgym_amd import BreedGym
+    from breedgym_amd.wrappers import KBestBreedGym, SimplifiedBreedGym
+
+    gm, geno = small
+    n = 30
+    bd, bo = twins(BreedGym, small)
+    W = SimplifiedBreedGym if which == "simplified" else KBestBreedGym
+    dev, ora = W(bd, individual_per_gen=n), W(bo, individual_per_gen=n)
+    od, _ = dev.reset(seed=7)
+    oo, _ = ora.reset(seed=7)
+    actions = ([{"n_bests": 10, "n_crosses": 20}, {"n_bests": 8, "n_crosses": 28}, {"n_bests": 2, "n_crosses": 1}]
+               if which == "simplified" else [5, 2, 8, 6])
+    for a in [None] + actions:
+        if a is not None:
+            od, rd, _, td, _ = dev.step(a)
+            oo, ro, _, to, _ = ora.step(a)
+            assert td == to and abs(rd - ro) <= 1e-5 * max(1.0, abs(ro))
+        assert len(od["GEBV"]) == n and len(od["corrcoef"]) == n
+        assert np.array_equal(u8(dev.unwrapped.population), u8(ora.unwrapped.population))
+        g64 = co.gebv(u8(ora.unwrapped.population), gm.marker_effects, want64=True)[1][:, 0]
+        assert gebv_close(od["GEBV"], g64)
+        c = np.asarray(od["corrcoef"])
+        assert np.allclose(c, np.asarray(oo["corrcoef"]), atol=1e-5) and np.all(np.abs(c) <= 1 + 1e-6)
+    for bad in (({"n_bests": 10, "n_crosses": 31}, {"n_bests": 2, "n_crosses": 10}, {"n_bests": 1, "n_crosses": 1},
+                 {"n_bests": 500, "n_crosses": 10}) if which == "simplified" else (1, 9)):
+        with pytest.raises(Exception):
+            dev.step(bad)
+
+
+def _pair_actions_restated(scores, n):
+    """vec_wrappers.py:100-112 in NumPy: top-n of the flattened pair scores, ceil(softmax * n) offspring each,
+    repeat, cut at n."""
+    out = np.empty((scores.shape[0], n, 2), np.int32)
+    for e in range(scores.shape[0]):
+        flat = scores[e].reshape(-1).astype(np.float32)
+        best = co.topk(flat, n)
+        v = flat[best]
+        ex = np.exp(v - v.max())
+        sm = ex / ex.sum(dtype=np.float64).astype(np.float32)
+        rep = np.ceil(sm * np.float32(n)).astype(np.int64)
+        pairs = np.stack((best // scores.shape[-1], best % scores.shape[-1]), 1)
+        out[e] = np.repeat(pairs, rep, axis=0)[:n]
+    return out
+
+
+def test_pair_scores_on_device_equals_oracle(small):  # reference tests/test_vec.py:186-204
+    from breedgym_amd.vector import PairScores
+
+    gm, geno = small
+    E, n = 3, 24
+    dev, ora = twins(PairScores, small, num_envs=E, individual_per_gen=n, num_generations=4, reward_shaping=True)
+    _, infd = dev.reset(seed=7)
+    _, info = ora.reset(seed=7)
+    for step in range(4):
+        g = np.asarray(info["GEBV"])[..., 0]
+        scores = g[:, :, None] + g[:, None, :]  # np.add.outer per env, as in the reference's test
+        od, rd, _, td, infd = dev.step(scores)
+        oo, ro, _, to, info = ora.step(scores)
+        low = np.asarray(infd["low_level_actions"])
+        assert np.array_equal(low, _pair_actions_restated(scores, n)), f"step {step}"
+        assert np.array_equal(low, np.asarray(info["low_level_actions"]))
+        assert np.array_equal(u8(od), u8(oo)) and np.array_equal(td, to)
+        assert np.allclose(rd, ro, rtol=1e-5)
+        assert gebv_close(np.asarray(infd["GEBV"]), np.asarray(info["GEBV"], np.float64))
+
+
+def test_wheat_breed_gym_on_device_equals_oracle(small):  # breeding_programs_env.py:39-72
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.vector.breeding_programs_env import WheatBreedGym
+
+    gm, geno = small
+    E, n = 2, 12
+    bd, bo = twins(VecBreedGym, small, num_envs=E, individual_per_gen=n, num_generations=3, reward_shaping=True)
+    dev = WheatBreedGym(bd, n_lines=8, plant_per_line=6, k_per_line=2)
+    ora = WheatBreedGym(bo, n_lines=8, plant_per_line=6, k_per_line=2)
+    pd_, infd = dev.reset(seed=4)
+    po, info = ora.reset(seed=4)
+    assert np.array_equal(u8(pd_), u8(po))
+    srng = np.random.default_rng(0)
+    for step in range(4):  # over the horizon and the autoreset
+        scores = srng.standard_normal((E, 8, 8)).astype(np.float32)  # (E, n_lines, n_lines)
+        pd_, rd, _, td, infd = dev.step(scores)
+        po, ro, _, to, info = ora.step(scores)
+        assert np.array_equal(u8(pd_), u8(po)), f"step {step}"
+        assert np.array_equal(td, to) and np.allclose(rd, ro, rtol=1e-5)
+        assert gebv_close(np.asarray(infd["GEBV"]), np.asarray(info["GEBV"], np.float64))
+        assert np.array_equal(bd.simulator.random_key, bo.simulator.random_key)
+        assert np.array_equal(bd.random_key, bo.random_key)
+        p = u8(pd_)
+        if not td.all():
+            assert np.array_equal(p[..., 0], p[..., 1])  # every kept plant is a doubled haploid
