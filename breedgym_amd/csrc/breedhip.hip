@@ -14,6 +14,7 @@
 #include <numeric>
 #include <vector>
 
+#include "gebv_bits.h"
 #include "gebv_mfma.h"
 #include "index_kernels.h"
 #include "packed_kernels.h"
@@ -75,8 +76,10 @@ struct bh_ctx {
   int last_buf = 1;
   // fixed-point marker effects for the int8-MFMA GEBV: one pack per group of <= 10 traits
   std::vector<bh::i32x4 *> d_Bpack;
+  std::vector<bh::i32x4 *> d_Bbits;  // the same digits in the operand order of gebv_bits_kernel
+  int32_t n_mc = 0;                  // 512-marker macro-chunks per row
   double *d_scale = nullptr;  // (T) 2^-s_t
-  uint4 *d_dig16 = nullptr;   // (T, nvec, 3) int16 digit planes of the fixed-point effects (packed_kernels.h)
+  uint4 *d_dig16 = nullptr;   // (T, 3, nvec) int16 digit planes of the fixed-point effects (packed_kernels.h)
   int32_t n_chunks = 0;
   int32_t *d_partial = nullptr;
   int64_t partial_cap = 0;  // int32 words
@@ -375,6 +378,65 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
     f.T = (int32_t)tn;
     f.Tstride = (int32_t)c->T;
     f.t0 = (int32_t)t0;
+    f.cols = bh::kGebvCols;
+    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+// GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
+// source row of every output row.
+#ifndef BH_GEBV_BITS_WGS  // tuning experiments only: workgroups the K slicing aims at
+#define BH_GEBV_BITS_WGS 1024
+#endif
+int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
+  constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
+  constexpr int F = 1;
+  const int64_t row_groups = (rows + 128 * F - 1) / (128 * F), rows_pad = row_groups * 128 * F;
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((BH_GEBV_BITS_WGS + row_groups - 1) / row_groups, c->n_mc));
+  const int64_t per_slice = (c->n_mc + slices - 1) / slices;
+  slices = (c->n_mc + per_slice - 1) / per_slice;
+  const int64_t need = slices * rows_pad * bh::kGebvCols;
+  if (need > c->partial_cap) {
+    BH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_partial) BH_HIP(hipFree(c->d_partial));
+    c->d_partial = nullptr;
+    c->partial_cap = 0;
+    BH_HIP(hipMalloc(&c->d_partial, (size_t)need * sizeof(int32_t)));
+    c->partial_cap = need;
+  }
+  for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
+    const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
+    const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;
+    bh::GebvBitsParams p{};
+    p.rows = reinterpret_cast<const uint8_t *>(d_rows);
+    p.idx = d_idx;
+    p.B = c->d_Bbits[g];
+    p.partial = c->d_partial;
+    p.row_bytes = (int64_t)16 * c->nw;
+    p.n_src = (int32_t)n_src;
+    p.n_rows = (int32_t)rows;
+    p.rows_pad = (int32_t)rows_pad;
+    p.n_mc = c->n_mc;
+    p.mc_per_slice = (int32_t)per_slice;
+    const dim3 grid((unsigned)row_groups, (unsigned)slices);
+    if (nt == 1)
+      hipLaunchKernelGGL((bh::gebv_bits_kernel<1, F>), grid, dim3(256), 0, c->stream, p);
+    else
+      hipLaunchKernelGGL((bh::gebv_bits_kernel<2, F>), grid, dim3(256), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+    bh::GebvFinishParams f{};
+    f.partial = c->d_partial;
+    f.scale = c->d_scale + t0;
+    f.gebv = d_gebv;
+    f.rows = (int32_t)rows;
+    f.rows_pad = (int32_t)rows_pad;
+    f.slices = (int32_t)slices;
+    f.T = (int32_t)tn;
+    f.Tstride = (int32_t)c->T;
+    f.t0 = (int32_t)t0;
+    f.cols = 32 * nt;
     hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
     BH_HIP(hipGetLastError());
   }
@@ -382,7 +444,10 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
 }
 
 // from this many traits on, the int8-MFMA GEBV pass beats GEBV fused into the row stream
-constexpr int kMfmaGebvMinTraits = 3;
+#ifndef BH_MFMA_GEBV_MIN_TRAITS  // tuning experiments only
+#define BH_MFMA_GEBV_MIN_TRAITS 3
+#endif
+constexpr int kMfmaGebvMinTraits = BH_MFMA_GEBV_MIN_TRAITS;
 bool use_mfma_gebv(const bh_ctx *c, int64_t rows) { return c->T >= kMfmaGebvMinTraits && rows >= 32; }
 
 // GEBV of rows already in memory, for trait chunks [t_begin, T)
@@ -575,7 +640,11 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
             long long d = ((fix % 65536) + 65536) % 65536;
             if (d >= 32768) d -= 65536;
             fix = (fix - d) / 65536;
+#if defined(BH_DIG_INTERLEAVED)
             dig[(size_t)(((t * c->nvec + (m >> 3)) * 3 + j) * 8 + (m & 7))] = (int16_t)d;
+#else
+            dig[(size_t)(((t * 3 + j) * c->nvec + (m >> 3)) * 8 + (m & 7))] = (int16_t)d;
+#endif
           }
         }
       BH_HIP_C(hipMalloc(&c->d_dig16, dig.size() * sizeof(int16_t)));
@@ -604,6 +673,32 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
       c->d_Bpack.push_back(dB);
       BH_HIP_C(hipMemcpy(dB, pack.data(), pack.size(), hipMemcpyHostToDevice));
     }
+    // the same digits in gebv_bits_kernel's order: [mc][q 4][ntile 2][j 4][lane (col, h)][16 markers]
+    // <-> marker 512 mc + 256 h + 64 q + 16 j + i; two macro-chunks of zeros behind the last one
+    // (the staging runs two steps ahead)
+    c->n_mc = (int32_t)((n_markers + 511) / 512);
+    std::vector<int8_t> bits((size_t)(c->n_mc + 1) * 32768);
+    for (int64_t g = 0; g < packs; ++g) {
+      std::fill(bits.begin(), bits.end(), (int8_t)0);
+      const int64_t t0 = g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, n_traits - t0);
+      for (int64_t m = 0; m < n_markers; ++m) {
+        const int64_t mc = m >> 9, rem = m & 511, h = rem >> 8, q = (rem >> 6) & 3, j = (rem >> 4) & 3, i = rem & 15;
+        for (int64_t t = 0; t < tn; ++t) {
+          long long fix = std::llround(std::ldexp((double)effects[m * n_traits + t0 + t], shift[(size_t)(t0 + t)]));
+          for (int d = 0; d < bh::kGebvDigits; ++d) {
+            long long dig = ((fix % 256) + 256) % 256;
+            if (dig >= 128) dig -= 256;
+            fix = (fix - dig) / 256;
+            const int64_t col = t * bh::kGebvDigits + d, nt = col >> 5, lane = (col & 31) + 32 * h;
+            bits[(size_t)((((((mc * 4 + q) * 2 + nt) * 4 + j) * 64 + lane) * 16) + i)] = (int8_t)dig;
+          }
+        }
+      }
+      bh::i32x4 *dB = nullptr;
+      BH_HIP_C(hipMalloc(&dB, bits.size()));
+      c->d_Bbits.push_back(dB);
+      BH_HIP_C(hipMemcpy(dB, bits.data(), bits.size(), hipMemcpyHostToDevice));
+    }
   }
 #undef BH_HIP_C
   *out = c;
@@ -620,6 +715,8 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_ctrB) (void)hipFree(c->d_ctrB);
   if (c->d_alwA) (void)hipFree(c->d_alwA);
   for (auto *b : c->d_Bpack)
+    if (b) (void)hipFree(b);
+  for (auto *b : c->d_Bbits)
     if (b) (void)hipFree(b);
   if (c->d_scale) (void)hipFree(c->d_scale);
   if (c->d_dig16) (void)hipFree(c->d_dig16);
@@ -759,7 +856,8 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     const int buf = c->last_buf;
     // GEBV inside the streaming launch (f64 VALU) for few traits; from 3 traits on the int8-MFMA
     // pass over the byte-layout offspring is faster -- when there are byte-layout offspring
-    const bool mfma_after = d_gebv && d_out_bytes && use_mfma_gebv(c, rows);
+    // (bit-plane rows: the pass over the packed offspring, gebv_bits.h)
+    const bool mfma_after = d_gebv && (packed || d_out_bytes) && use_mfma_gebv(c, rows);
     const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
     const int tcount = fused ? (int32_t)c->T : 0;
     // run ahead: the next generation's masks need only the advanced key and the batch size, so
@@ -831,10 +929,11 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       c->pf.dh = dh;
     }
     if (d_gebv && !fused) {
-      if (d_out_bytes)
-        rc = gebv_chunks(c, d_out_bytes, rows, d_gebv, 0);
+      if (packed)
+        rc = mfma_after ? gebv_bits(c, d_out_packed, rows, nullptr, rows, d_gebv)
+                        : packed_gebv_chunks(c, d_out_packed, rows, d_gebv, 0);
       else
-        rc = packed_gebv_chunks(c, d_out_packed, rows, d_gebv, 0);
+        rc = gebv_chunks(c, d_out_bytes, rows, d_gebv, 0);
       if (rc) return rc;
     }
     // the reward of vec_env.py:97: a 2 us reduction kernel behind the cross launch (an in-launch
@@ -899,14 +998,15 @@ int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const i
   p.gebv = d_gebv;
   p.n_pool = (int32_t)src_rows;
   p.n_rows = (int32_t)n_rows;
-  const bool mfma_after = d_gebv && d_out_bytes && use_mfma_gebv(c, n_rows);
+  const bool mfma_after = d_gebv && use_mfma_gebv(c, n_rows);
   const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
   p.tcount = fused ? (int32_t)c->T : 0;
   if (p.tcount > 0 || d_out_packed || d_out_bytes)
     if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;
   if (d_gebv && !fused) {
-    if (d_out_bytes) return gebv_chunks(c, d_out_bytes, n_rows, d_gebv, 0);
-    // no byte rows to run the matrix-core pass on: f64 passes over the packed rows, through the index
+    // the matrix-core pass straight over the source rows, through the index (gebv_bits.h)
+    if (mfma_after) return gebv_bits(c, d_src, src_rows, d_idx, n_rows, d_gebv);
+    // few rows or more than eight traits: f64 passes over the packed rows, through the index
     for (int t0 = 0; t0 < c->T; t0 += kMaxFusedTraits) {
       bh::PackedParams q = p;
       q.outp = nullptr;

@@ -1,0 +1,185 @@
+// GEBV straight from bit-plane rows on the matrix cores, exactly.
+//
+//   GEBV[i, t] = sum_m dosage[i, m] * effects[m, t],   dosage = allele 0 + allele 1 of marker m
+//
+// with the effects in the same fixed point as gebv_mfma.h (six balanced base-256 digits of
+// round(e * 2^s_t), exact int32 sums per digit, recombined in int64 by gebv_finish_kernel).  What is
+// read per individual is its bit-plane row -- M/4 bytes instead of the 2M of the byte layout -- so the
+// pass is no longer a question of genotype bytes: at 2048 x 100k x 8 traits the rows are 51 MB.  What
+// it costs is (i) turning bits into int8 operands, (ii) the digit operand of every MFMA (1 KB per
+// 32 x 32 x 32 product, 8x the genotype bytes it meets), (iii) the MFMAs.  So:
+//
+//   * a workgroup is four waves, each with its own 32-row tile(s), all walking the same slice of the
+//     marker axis: the digit operands of a step are staged ONCE per workgroup in LDS (two buffers, the
+//     global loads of step k+2 in flight while step k computes, one barrier per step) and read by all
+//     four waves -- a quarter of the L2 traffic and none of its latency in the MFMA chain;
+//   * a lane (r = row of the tile, h = half) owns 64 contiguous bytes of its row per 512-marker
+//     macro-chunk (lanes r and r+32 share a 128-byte line; the four 16-byte loads are issued together, a
+//     macro-chunk ahead); one dword of it = 16 markers = the A operand of one MFMA:
+//         d = x - ((x >> 1) & 0x5555...)          16 two-bit dosages
+//         per byte of d:  (y | y << 12) & 0x000F000F,  (y | y << 6) & 0x03030303   -> 4 dosage bytes
+//     23 integer instructions per 16 markers and 32 rows;
+//   * the K axis is cut into slices over blockIdx.y (rows alone never fill the chip: 2048 rows are 64
+//     tiles); every slice leaves an int32 slab, gebv_finish_kernel adds the slabs.
+//
+// Marker order inside an MFMA is whatever the lanes hold -- a sum over K does not care -- as long as
+// the digit operand is packed to match: macro-chunk mc, step q (0..3), MFMA j (0..3), lane (c, h),
+// byte i  <->  digit column c (+32 per column tile) of marker 512 mc + 256 h + 64 q + 16 j + i.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gebv_mfma.h"
+
+namespace bh {
+
+struct GebvBitsParams {
+  const uint8_t *rows;  // (n_src, row_bytes) bit-plane rows
+  const int32_t *idx;   // (n_rows) source row of output row i, or null (= i)
+  const i32x4 *B;       // [mc][q 4][ntile 2][j 4][lane 64] 16 int8 each
+  int32_t *partial;     // [slices][rows_pad][32 * NT] int32
+  int64_t row_bytes;    // 16 * ceil(M / 64)
+  int32_t n_src, n_rows, rows_pad;
+  int32_t n_mc;          // ceil(M / 512)
+  int32_t mc_per_slice;
+};
+
+// 16 markers (one dword of a bit-plane row: bits 2k, 2k+1 = the alleles of marker k) -> 16 dosage bytes
+__device__ __forceinline__ i32x4 dosage16_from_bits(uint32_t x) {
+  const uint32_t d = x - ((x >> 1) & 0x55555555u);  // 16 fields of 2 bits: 0, 1, 2
+  i32x4 a;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t y = (d >> (8 * q)) & 0xffu;
+    y = (y | (y << 12)) & 0x000F000Fu;
+    y = (y | (y << 6)) & 0x03030303u;
+    a[q] = (int)y;
+  }
+  return a;
+}
+
+template <int NT, int F>
+__global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) {
+  static_assert(NT == 1 || NT == 2, "one or two 32-column tiles");
+  constexpr int STEP_V = NT * 4 * 64;  // i32x4 per step in LDS
+  __shared__ i32x4 ldsB[2][STEP_V];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int slice = blockIdx.y;
+  const int mc_begin = slice * p.mc_per_slice;
+  const int mc_end = min(p.n_mc, mc_begin + p.mc_per_slice);
+  const int n_steps = (mc_end - mc_begin) * 4;  // > 0 by construction of the grid
+
+  // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row
+  // (its lanes re-read the last row; nothing of it is used by gebv_finish_kernel)
+  const int tile0 = (blockIdx.x * 4 + wave) * F;
+  const uint8_t *pa[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    int row = min((tile0 + f) * 32 + r, p.n_rows - 1);
+    if (p.idx) {
+      int s = p.idx[row];
+      if (s < 0) s += p.n_src;
+      row = s < 0 ? 0 : (s >= p.n_src ? p.n_src - 1 : s);
+    }
+    pa[f] = p.rows + (int64_t)row * p.row_bytes + 64 * h;
+  }
+
+  i32x16 acc[F][NT];
+#pragma unroll
+  for (int f = 0; f < F; ++f)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[f][j][k] = 0;
+
+  struct Chunk {
+    uint4 g[F][4];
+  };
+  auto load_chunk = [&](int mc, Chunk &c) {
+    const int64_t off = (int64_t)mc * 128 + 64 * h;  // this lane's 64 bytes of the macro-chunk
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // a 16-byte piece is wholly inside the row or wholly beyond it (row_bytes % 16 == 0)
+        const bool in = mc < mc_end && off + 16 * q + 16 <= p.row_bytes;
+        c.g[f][q] = in ? *reinterpret_cast<const uint4 *>(pa[f] + (int64_t)mc * 128 + 16 * q) : make_uint4(0, 0, 0, 0);
+      }
+  };
+  // digit operands of step k of this slice -> registers (NT 16-byte pieces per thread)
+  i32x4 breg[NT];
+  auto load_b = [&](int k) {
+    if (k < n_steps) {
+      const i32x4 *src = p.B + ((int64_t)(mc_begin * 4 + k) * 2) * 256;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) breg[u] = src[u * 256 + tid];
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) ldsB[buf][u * 256 + tid] = breg[u];
+  };
+  auto step = [&](int buf, const Chunk &c, int q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      i32x4 b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = ldsB[buf][(t * 4 + j) * 64 + lane];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const uint4 g = c.g[f][q];
+        const uint32_t x = j == 0 ? g.x : j == 1 ? g.y : j == 2 ? g.z : g.w;
+        const i32x4 a = dosage16_from_bits(x);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[f][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t], acc[f][t], 0, 0, 0);
+      }
+    }
+  };
+
+  Chunk c0, c1;
+  load_chunk(mc_begin, c0);
+  load_b(0);
+  store_b(0);
+  load_b(1);
+  __syncthreads();
+  int k = 0;
+  for (int mc = mc_begin; mc < mc_end; mc += 2) {
+    load_chunk(mc + 1, c1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q, ++k) {
+      store_b((k + 1) & 1);  // step k+1's digits; that buffer was last read in step k-1, before the barrier
+      load_b(k + 2);
+      step(k & 1, c0, q);
+      __syncthreads();
+    }
+    if (mc + 1 < mc_end) {
+      load_chunk(mc + 2, c0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q, ++k) {
+        store_b((k + 1) & 1);
+        load_b(k + 2);
+        step(k & 1, c1, q);
+        __syncthreads();
+      }
+    }
+  }
+
+  // C/D layout of the 32x32 MFMAs: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  constexpr int COLS = 32 * NT;
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const int row0 = (tile0 + f) * 32;
+    if (row0 >= p.rows_pad) continue;
+    int32_t *out = p.partial + ((int64_t)slice * p.rows_pad + row0) * COLS;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = (kk & 3) + 8 * (kk >> 2) + 4 * h;
+        out[(int64_t)row * COLS + 32 * t + r] = acc[f][t][kk];
+      }
+  }
+}
+
+}  // namespace bh

@@ -125,10 +125,11 @@ __global__ __launch_bounds__(256) void gebv_mfma_kernel(const GebvMfmaParams p) 
 }
 
 struct GebvFinishParams {
-  const int32_t *partial;  // [slices][rows_pad][64]
+  const int32_t *partial;  // [slices][rows_pad][cols]
   const double *scale;     // (T) 2^-s_t
   float *gebv;             // (rows, Tstride)
   int32_t rows, rows_pad, slices, T, Tstride, t0;
+  int32_t cols;            // slab row pitch in int32: 64 (gebv_mfma_kernel) or 32 * NT (gebv_bits_kernel)
 };
 
 // one wave per row, lane = column: the slabs are read in whole 256-byte rows; the six digit sums
@@ -138,8 +139,10 @@ __global__ __launch_bounds__(256) void gebv_finish_kernel(const GebvFinishParams
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   long long s = 0;
-  const int32_t *src = p.partial + (int64_t)row * kGebvCols + lane;
-  for (int sl = 0; sl < p.slices; ++sl) s += src[(int64_t)sl * p.rows_pad * kGebvCols];
+  if (lane < p.cols) {
+    const int32_t *src = p.partial + (int64_t)row * p.cols + lane;
+    for (int sl = 0; sl < p.slices; ++sl) s += src[(int64_t)sl * p.rows_pad * p.cols];
+  }
   long long total = 0;
 #pragma unroll
   for (int d = 0; d < kGebvDigits; ++d) {

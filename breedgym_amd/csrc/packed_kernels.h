@@ -26,7 +26,7 @@ struct PackedParams {
   float *gebv;          // (rows, T) or null
   const uint8_t *Z;     // cross: (B, zpitch) masks from the mask role
   const double *eff;    // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
-  const uint4 *dig;     // (T, nvec, 3) 16-byte blocks: digit j of trait t for the 8 markers of vector v, as int16
+  const uint4 *dig;     // (T, 3, nvec) 16-byte blocks: digit j of trait t for the 8 markers of vector v, as int16
   const double *scale;  // (T) 2^-s_t of the fixed-point effects
   int64_t pitch;        // bytes per byte-layout row
   int64_t effPitch;
@@ -269,10 +269,17 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     uint4 dg[TT][3];
 #pragma unroll
     for (int q = 0; q < TT; ++q) {
+#if defined(BH_DIG_INTERLEAVED)  // tuning experiments only: digits of a vector side by side (lane stride 48 B)
       const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
       dg[q][0] = dp[0];
       dg[q][1] = dp[1];
       dg[q][2] = dp[2];
+#else  // one plane per digit: a wave's load is 1 KB contiguous
+      const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vv;
+      dg[q][0] = dp[0];
+      dg[q][1] = dp[p.nvec];
+      dg[q][2] = dp[2 * (int64_t)p.nvec];
+#endif
     }
 #endif
     load_words(base + 64, next);
