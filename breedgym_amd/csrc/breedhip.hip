@@ -388,11 +388,14 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
 #ifndef BH_GEBV_BITS_WGS  // tuning experiments only: workgroups the K slicing aims at
-#define BH_GEBV_BITS_WGS 1024
+#define BH_GEBV_BITS_WGS 512
 #endif
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
-  constexpr int F = 1;
+#ifndef BH_GEBV_BITS_F  // tuning experiments only: 32-row tiles per wave
+#define BH_GEBV_BITS_F 1
+#endif
+  constexpr int F = BH_GEBV_BITS_F;
   const int64_t row_groups = (rows + 128 * F - 1) / (128 * F), rows_pad = row_groups * 128 * F;
   int64_t slices = std::max<int64_t>(1, std::min<int64_t>((BH_GEBV_BITS_WGS + row_groups - 1) / row_groups, c->n_mc));
   const int64_t per_slice = (c->n_mc + slices - 1) / slices;
@@ -449,6 +452,14 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
 #endif
 constexpr int kMfmaGebvMinTraits = BH_MFMA_GEBV_MIN_TRAITS;
 bool use_mfma_gebv(const bh_ctx *c, int64_t rows) { return c->T >= kMfmaGebvMinTraits && rows >= 32; }
+// bit-plane rows: the matrix-core pass (gebv_bits.h) also for one or two traits once the rows are long --
+// at 100k markers it takes a quarter of the f64 stream's time (profiles/r02_gebv_bits.txt)
+#ifndef BH_BITS_GEBV_MIN_MARKERS  // tuning experiments only
+#define BH_BITS_GEBV_MIN_MARKERS 16385
+#endif
+bool use_bits_gebv(const bh_ctx *c, int64_t rows) {
+  return rows >= 32 && (c->T >= kMfmaGebvMinTraits || c->M >= BH_BITS_GEBV_MIN_MARKERS);
+}
 
 // GEBV of rows already in memory, for trait chunks [t_begin, T)
 int gebv_chunks(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
@@ -674,7 +685,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
       BH_HIP_C(hipMemcpy(dB, pack.data(), pack.size(), hipMemcpyHostToDevice));
     }
     // the same digits in gebv_bits_kernel's order: [mc][q 4][ntile 2][j 4][lane (col, h)][16 markers]
-    // <-> marker 512 mc + 256 h + 64 q + 16 j + i; two macro-chunks of zeros behind the last one
+    // <-> marker 512 mc + 256 h + 64 q + 16 j + i (operand byte 4 (i & 3) + (i >> 2)); a macro-chunk of zeros behind the last one
     // (the staging runs two steps ahead)
     c->n_mc = (int32_t)((n_markers + 511) / 512);
     std::vector<int8_t> bits((size_t)(c->n_mc + 1) * 32768);
@@ -690,7 +701,8 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
             if (dig >= 128) dig -= 256;
             fix = (fix - dig) / 256;
             const int64_t col = t * bh::kGebvDigits + d, nt = col >> 5, lane = (col & 31) + 32 * h;
-            bits[(size_t)((((((mc * 4 + q) * 2 + nt) * 4 + j) * 64 + lane) * 16) + i)] = (int8_t)dig;
+            // operand byte of local marker i: dword i & 3, byte i >> 2 (dosage16_from_bits)
+            bits[(size_t)((((((mc * 4 + q) * 2 + nt) * 4 + j) * 64 + lane) * 16) + 4 * (i & 3) + (i >> 2))] = (int8_t)dig;
           }
         }
       }
@@ -857,7 +869,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // GEBV inside the streaming launch (f64 VALU) for few traits; from 3 traits on the int8-MFMA
     // pass over the byte-layout offspring is faster -- when there are byte-layout offspring
     // (bit-plane rows: the pass over the packed offspring, gebv_bits.h)
-    const bool mfma_after = d_gebv && (packed || d_out_bytes) && use_mfma_gebv(c, rows);
+    const bool mfma_after = d_gebv && (packed ? use_bits_gebv(c, rows) : use_mfma_gebv(c, rows));
     const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
     const int tcount = fused ? (int32_t)c->T : 0;
     // run ahead: the next generation's masks need only the advanced key and the batch size, so
@@ -998,7 +1010,7 @@ int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const i
   p.gebv = d_gebv;
   p.n_pool = (int32_t)src_rows;
   p.n_rows = (int32_t)n_rows;
-  const bool mfma_after = d_gebv && use_mfma_gebv(c, n_rows);
+  const bool mfma_after = d_gebv && use_bits_gebv(c, n_rows);
   const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
   p.tcount = fused ? (int32_t)c->T : 0;
   if (p.tcount > 0 || d_out_packed || d_out_bytes)

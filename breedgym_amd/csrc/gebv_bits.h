@@ -17,14 +17,14 @@
 //     macro-chunk (lanes r and r+32 share a 128-byte line; the four 16-byte loads are issued together, a
 //     macro-chunk ahead); one dword of it = 16 markers = the A operand of one MFMA:
 //         d = x - ((x >> 1) & 0x5555...)          16 two-bit dosages
-//         per byte of d:  (y | y << 12) & 0x000F000F,  (y | y << 6) & 0x03030303   -> 4 dosage bytes
-//     23 integer instructions per 16 markers and 32 rows;
+//         operand dword q = (d >> 2q) & 0x03030303   (byte b = marker q + 4b: any order will do)
+//     10 integer instructions per 16 markers and 32 rows;
 //   * the K axis is cut into slices over blockIdx.y (rows alone never fill the chip: 2048 rows are 64
 //     tiles); every slice leaves an int32 slab, gebv_finish_kernel adds the slabs.
 //
 // Marker order inside an MFMA is whatever the lanes hold -- a sum over K does not care -- as long as
 // the digit operand is packed to match: macro-chunk mc, step q (0..3), MFMA j (0..3), lane (c, h),
-// byte i  <->  digit column c (+32 per column tile) of marker 512 mc + 256 h + 64 q + 16 j + i.
+// byte i  <->  digit column c (+32 per column tile) of marker 512 mc + 256 h + 64 q + 16 j + (i >> 2) + 4 (i & 3).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,17 +44,14 @@ struct GebvBitsParams {
   int32_t mc_per_slice;
 };
 
-// 16 markers (one dword of a bit-plane row: bits 2k, 2k+1 = the alleles of marker k) -> 16 dosage bytes
+// 16 markers (one dword of a bit-plane row: bits 2k, 2k+1 = the alleles of marker k) -> 16 dosage bytes.
+// The order of the bytes is free (the digit operand is packed to match), so no field is moved further than
+// a shift of the whole dword: byte b of dword q is the dosage of marker q + 4 b.  10 instructions.
 __device__ __forceinline__ i32x4 dosage16_from_bits(uint32_t x) {
   const uint32_t d = x - ((x >> 1) & 0x55555555u);  // 16 fields of 2 bits: 0, 1, 2
   i32x4 a;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    uint32_t y = (d >> (8 * q)) & 0xffu;
-    y = (y | (y << 12)) & 0x000F000Fu;
-    y = (y | (y << 6)) & 0x03030303u;
-    a[q] = (int)y;
-  }
+  for (int q = 0; q < 4; ++q) a[q] = (int)((d >> (2 * q)) & 0x03030303u);
   return a;
 }
 

@@ -141,7 +141,16 @@ __global__ __launch_bounds__(256) void gebv_finish_kernel(const GebvFinishParams
   long long s = 0;
   if (lane < p.cols) {
     const int32_t *src = p.partial + (int64_t)row * p.cols + lane;
-    for (int sl = 0; sl < p.slices; ++sl) s += src[(int64_t)sl * p.rows_pad * p.cols];
+    const int64_t stride = (int64_t)p.rows_pad * p.cols;
+    int sl = 0;
+    for (; sl + 8 <= p.slices; sl += 8) {  // eight slabs in flight
+      int32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(sl + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sl < p.slices; ++sl) s += src[sl * stride];
   }
   long long total = 0;
 #pragma unroll

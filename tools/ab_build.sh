@@ -5,5 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_ab
 name=$1; shift
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ibreedgym_amd/csrc "$@" -w -o tools/_ab/$name tools/ablate_packed.cpp breedgym_amd/csrc/breedhip.hip
+drv=tools/ablate_packed.cpp
+if [ "$1" = "--gebv" ]; then drv=tools/ablate_gebv.cpp; shift; fi
+hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ibreedgym_amd/csrc "$@" -w -o tools/_ab/$name $drv breedgym_amd/csrc/breedhip.hip
 echo built tools/_ab/$name

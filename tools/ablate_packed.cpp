@@ -20,7 +20,9 @@ int main(int argc, char **argv) {
   bh_alloc(ctx, rows * pitch, (void **)&bytes); bh_alloc(ctx, rows * pitch, (void **)&ob);
   bh_alloc(ctx, rows * pp, (void **)&pool); bh_alloc(ctx, rows * pp, (void **)&out);
   bh_alloc(ctx, rows * 2 * 4, (void **)&idx); bh_alloc(ctx, rows * 4, (void **)&gebv);
-  std::vector<uint8_t> h(rows * pitch); for (auto &b : h) b = rand() & 1;
+  std::vector<uint8_t> h(rows * pitch);
+  { uint64_t s = 88172645463325252ull; uint64_t *w = reinterpret_cast<uint64_t *>(h.data());
+    for (size_t i = 0; i < h.size() / 8; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; w[i] = s & 0x0101010101010101ull; } }
   std::vector<int32_t> hi(rows * 2); for (auto &v : hi) v = rand() % n;
   bh_memcpy_h2d(ctx, bytes, h.data(), h.size()); bh_memcpy_h2d(ctx, idx, hi.data(), hi.size() * 4);
   bh_pack(ctx, bytes, rows, pool); bh_sync(ctx);
