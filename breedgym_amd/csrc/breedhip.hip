@@ -243,10 +243,15 @@ int launch_cross_mw(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp
 #define BH_PACKED_R 2
 #endif
 constexpr int kRowsPerWavePacked = BH_PACKED_R;
+#ifndef BH_LONG_R  // rows a wave interleaves in the long-row stream (tuning experiments only)
+#define BH_LONG_R 1
+#endif
+constexpr int kRowsPerWaveLong = BH_LONG_R;
 
 template <int TT, int MW, int R>
 int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
-  rp.n_blocks = (rp.n_rows + 4 * R - 1) / (4 * R);
+  const int per_wave = R * std::max(1, rp.seq);
+  rp.n_blocks = (rp.n_rows + 4 * per_wave - 1) / (4 * per_wave);
   const size_t lds = (size_t)mp.group_lds * (4 / MW);
   const int grid = MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks);
   hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
@@ -268,7 +273,8 @@ int launch_pcross_mw(bh_ctx *c, const bh::PackedParams &rp, const bh::MaskParams
 
 template <int TT, int MODE, int R>
 int launch_prow(const bh_ctx *c, bh::PackedParams p) {
-  p.n_blocks = (p.n_rows + 4 * R - 1) / (4 * R);
+  const int per_wave = R * std::max(1, p.seq);
+  p.n_blocks = (p.n_rows + 4 * per_wave - 1) / (4 * per_wave);
   hipLaunchKernelGGL((bh::packed_row_kernel<TT, MODE, R>), dim3((unsigned)p.n_blocks), dim3(256), 0, c->stream, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_row_kernel launch: %s", hipGetErrorString(e));
@@ -307,6 +313,17 @@ int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
   BH_HIP(hipMalloc(&c->d_Z[buf], (size_t)bytes));
   c->z_cap[buf] = bytes;
   return BH_OK;
+}
+
+// Long bit-plane rows without GEBV in the stream (it follows as the matrix-core pass): a wave streams
+// its rows one after the other, so that about BH_LONG_STREAMS rows are being written at any time
+// (packed_stream_role).  0 = the ordinary stream.
+#ifndef BH_LONG_STREAMS  // tuning experiments only
+#define BH_LONG_STREAMS 4096
+#endif
+int long_row_turns(const bh_ctx *c, int64_t rows) {
+  if (c->M <= 16384 || rows < 2 * BH_LONG_STREAMS) return 0;
+  return (int)std::min<int64_t>(16, rows / BH_LONG_STREAMS);
 }
 
 int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 ? 2 : tcount <= 4 ? 4 : 8; }
@@ -869,7 +886,11 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // GEBV inside the streaming launch (f64 VALU) for few traits; from 3 traits on the int8-MFMA
     // pass over the byte-layout offspring is faster -- when there are byte-layout offspring
     // (bit-plane rows: the pass over the packed offspring, gebv_bits.h)
-    const bool mfma_after = d_gebv && (packed ? use_bits_gebv(c, rows) : use_mfma_gebv(c, rows));
+    // one or two traits leave the stream only where the long-row stream takes over (many long bit-plane rows
+    // next to four-wave mask groups): elsewhere the digit products inside the stream are cheaper than a pass
+    const bool long_stream = packed && (!c->prefetch || mask_waves_for_runahead(c, B) == 4) && long_row_turns(c, rows) > 1;
+    const bool mfma_after =
+        d_gebv && (packed ? (c->T >= kMfmaGebvMinTraits ? use_bits_gebv(c, rows) : long_stream) : use_mfma_gebv(c, rows));
     const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
     const int tcount = fused ? (int32_t)c->T : 0;
     // run ahead: the next generation's masks need only the advanced key and the batch size, so
@@ -897,13 +918,19 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.n_rows = (int32_t)rows;
       p.rng_shared = shared;
       p.tcount = tcount;
+      const int turns = (tcount == 0 && (!run_ahead || mw == 4)) ? long_row_turns(c, rows) : 0;
+      p.seq = turns;
       if (run_ahead) {
         if (mw == 1)
           rc = wide ? launch_pcross_mw<1, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<1, 1>(c, p, mp, tt_for(tcount));
+        else if (turns > 1)
+          rc = launch_pcross_mw<4, kRowsPerWaveLong>(c, p, mp, 0);
         else
           rc = wide ? launch_pcross_mw<4, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<4, 1>(c, p, mp, tt_for(tcount));
+      } else if (turns > 1) {
+        rc = launch_prow_r<bh::MODE_CROSS, kRowsPerWaveLong>(c, p, 0);
       } else {
         rc = launch_prow_mode<bh::MODE_CROSS>(c, p, tt_for(tcount));
       }
@@ -1010,11 +1037,19 @@ int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const i
   p.gebv = d_gebv;
   p.n_pool = (int32_t)src_rows;
   p.n_rows = (int32_t)n_rows;
-  const bool mfma_after = d_gebv && use_bits_gebv(c, n_rows);
+  const bool writes = d_out_packed || d_out_bytes;
+  const bool mfma_after =
+      d_gebv && use_bits_gebv(c, n_rows) &&
+      (c->T >= kMfmaGebvMinTraits || !writes || (d_out_packed && long_row_turns(c, n_rows) > 1));
   const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
   p.tcount = fused ? (int32_t)c->T : 0;
-  if (p.tcount > 0 || d_out_packed || d_out_bytes)
-    if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;
+  if (p.tcount > 0 || d_out_packed || d_out_bytes) {
+    const int turns = (p.tcount == 0 && d_out_packed) ? long_row_turns(c, n_rows) : 0;
+    p.seq = turns;
+    if (int rc = turns > 1 ? launch_prow_r<bh::MODE_GATHER, kRowsPerWaveLong>(c, p, 0)
+                           : launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount)))
+      return rc;
+  }
   if (d_gebv && !fused) {
     // the matrix-core pass straight over the source rows, through the index (gebv_bits.h)
     if (mfma_after) return gebv_bits(c, d_src, src_rows, d_idx, n_rows, d_gebv);

@@ -18,6 +18,11 @@
 
 namespace bh {
 
+#ifndef BH_LONG_VPT  // vectors per lane and trip in the long-row stream (tuning experiments only)
+#define BH_LONG_VPT 2
+#endif
+constexpr int kLongRowVectors = BH_LONG_VPT;
+
 struct PackedParams {
   const uint16_t *src;  // cross: (E, n_pool, nvp) packed pool; gather: (n_pool, nvp)
   uint16_t *outp;       // (rows, nvp) packed rows out, or null
@@ -38,6 +43,7 @@ struct PackedParams {
   int32_t n_blocks;
   int32_t T, t0, tcount;
   int32_t rng_shared;
+  int32_t seq;  // row groups a wave of packed_stream_role streams one after the other (>= 1)
 };
 
 // dword k of byte-layout vector v from its packed word: bits 4k .. 4k+3 are its four bytes; the
@@ -50,15 +56,14 @@ __device__ __forceinline__ uint4 expand_vector(uint32_t o16) {
   return make_uint4(expand_dword(o16, 0), expand_dword(o16, 1), expand_dword(o16, 2), expand_dword(o16, 3));
 }
 
-// The offspring word of a cross, 8 markers at once.  Allele 0 of the offspring is the gamete of
-// parent 0: its allele-0 bit (even position) where the mask bit is 0, its allele-1 bit where it is 1;
-// allele 1 is the gamete of parent 1 under the odd mask bits.
+// The offspring word of a cross, 8 markers at once.  Allele 0 of the offspring (even bit) is the gamete of
+// parent 0: its allele-0 bit where the mask bit is 0, its allele-1 bit where it is 1; allele 1 (odd bit) is
+// the gamete of parent 1 under the odd mask bits.  Three bit-field inserts: at the even positions of
+// bfi(z, p0 >> 1, p0) the even mask bits choose between p0's odd and even bits, at the odd positions of
+// bfi(z, p1, p1 << 1) the odd mask bits choose between p1's odd and even bits; the third keeps each half.
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 __device__ __forceinline__ uint32_t cross16(uint32_t p0, uint32_t p1, uint32_t z) {
-  const uint32_t e0 = p0 & 0x5555u, o0 = (p0 >> 1) & 0x5555u;
-  const uint32_t e1 = p1 & 0x5555u, o1 = (p1 >> 1) & 0x5555u;
-  const uint32_t g0 = e0 ^ ((e0 ^ o0) & z);         // even bits; z's odd bits fall on zeros
-  const uint32_t g1 = e1 ^ ((e1 ^ o1) & (z >> 1));  // even bits
-  return g0 | (g1 << 1);
+  return bfi(0x5555u, bfi(z, p0 >> 1, p0), bfi(z, p1, p1 << 1)) & 0xffffu;
 }
 
 // One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
@@ -174,214 +179,195 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 }
 
 // The row role of the fused launch next to four-wave mask groups, and the stream of the standalone
-// launches that write packed rows with their GEBV (reset's founder gather), software-pipelined like
-// row_role_pipelined (row_kernels.h): the 2-byte words of trip t+1 are requested before trip t's
-// stores and the marker effects of trip t before those, no wait covers a store, the body is
-// branch-free (lanes past the end of the row redo the last vector, dead row slots redo row c0; the few
-// padding words of a packed row are written behind the loop), no priority raise.
-template <int TT, int MODE, int R, bool OBS>
+// launches that write packed rows (reset's founder gather), software-pipelined like row_role_pipelined
+// (row_kernels.h): the 2-byte words of trip t+1 are requested before trip t's stores and the marker
+// effects of trip t before those, no wait covers a store, the body is branch-free (lanes past the end of
+// the row redo the last vector, dead row slots redo row c0; the few padding words of a packed row are
+// written behind the loop), no priority raise.
+// TT = 0: no GEBV in the stream (long rows: the matrix-core pass over the packed offspring follows,
+// gebv_bits.h).  p.seq row groups per wave, one after the other: long rows are HBM-resident, and the
+// fewer row streams the chip writes at a time the better the DRAM pages are used -- 8192 streams of
+// 100k markers store at 2.4 TB/s, 2048 at 7.7 (profiles/r01_exp_long_rows_streams.txt).
+template <int TT, int MODE, int R, bool OBS, int VPT = 1>
 __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave) {
-  static_assert(TT == 1 || TT == 2, "effects are held in registers across the trip");
+  static_assert(TT >= 0 && TT <= 2, "effects are held in registers across the trip");
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
+  static_assert(VPT == 1 || TT == 0, "several vectors per lane and trip only without GEBV in the stream");
+  constexpr int NT = TT > 0 ? TT : 1;
   const int lane = threadIdx.x & 63;
-  const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
-  if (c0 >= p.n_rows) return;
-
-  const uint16_t *src0[R], *src1[R], *Z16[R];
-  uint16_t *dstp[R];
-  uint8_t *dstb[R];
-  bool live[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    live[r] = c0 + r < p.n_rows;
-    const int c = live[r] ? c0 + r : c0;
-    src1[r] = nullptr;
-    Z16[r] = nullptr;
-    if constexpr (MODE == MODE_CROSS) {
-      const int e = c / p.n_out, i = c - e * p.n_out;
-      const int i0 = norm_index(p.idx[2 * (int64_t)c], p.n_pool);
-      const int i1 = norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool);
-      src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
-      src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
-      Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
-    } else {
-      src0[r] = p.src + (int64_t)(p.idx ? norm_index(p.idx[c], p.n_pool) : c) * p.nvp;
-    }
-    dstp[r] = p.outp + (int64_t)c * p.nvp;
-    dstb[r] = OBS ? p.outb + (int64_t)c * p.pitch : nullptr;
-  }
-
-#if defined(BH_GEBV_F64)  // tuning experiments only: the f64 sum of the plain roles
-  double acc[R][TT];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int t = 0; t < TT; ++t) acc[r][t] = 0.0;
-#else
-  // GEBV in exact fixed point: the effects are round(e * 2^s_t) cut into three balanced base-65536
-  // digits (as gebv_mfma.h cuts them into six base-256 ones), the dosages of a marker pair are the
-  // two int16 halves of (w + (w >> 8)) & 0x00FF00FF, and a v_dot2_i32_i16 per pair and digit replaces
-  // eight conversions and eight f64 FMAs per vector.  |digit| <= 2^15 and dosage <= 2, so a lane's
-  // int32 sums stay below 2^31 for rows of up to 2^21 markers (bh_max_markers() is 2^18).
-  int acc[R][TT][3];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int t = 0; t < TT; ++t)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[r][t][j] = 0;
+  const int seq = p.seq > 1 ? p.seq : 1;
+#if defined(BH_LONG_ROW_PRIO)  // tuning experiments only
+  if constexpr (TT == 0) __builtin_amdgcn_s_setprio(BH_LONG_ROW_PRIO);
 #endif
+  const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R * seq);
+  for (int sq = 0; sq < seq; ++sq) {
+    const int c0 = first + sq * R;
+    if (c0 >= p.n_rows) return;
 
-  const int last = p.nvec - 1;
-  struct Words {
-    uint32_t a[R], b[R], z[R];
-  };
-  auto load_words = [&](int base, Words &w) {
-    int v = base + lane;
-    v = v < last ? v : last;
+    const uint16_t *src0[R], *src1[R], *Z16[R];
+    uint16_t *dstp[R];
+    uint8_t *dstb[R];
+    bool live[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      w.a[r] = src0[r][v];
+      live[r] = c0 + r < p.n_rows;
+      const int c = live[r] ? c0 + r : c0;
+      src1[r] = nullptr;
+      Z16[r] = nullptr;
+      // the parents' indices are wave-uniform; said so, every row base is a scalar and the lanes address
+      // with one 32-bit offset (no 64-bit address arithmetic, a third of the registers)
       if constexpr (MODE == MODE_CROSS) {
-        w.b[r] = src1[r][v];
-        w.z[r] = Z16[r][v];
+        const int e = c / p.n_out, i = c - e * p.n_out;
+        const int i0 = __builtin_amdgcn_readfirstlane(norm_index(p.idx[2 * (int64_t)c], p.n_pool));
+        const int i1 = __builtin_amdgcn_readfirstlane(norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool));
+        src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
+        src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
+        Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
       } else {
-        w.b[r] = 0;
-        w.z[r] = 0;
+        const int i0 = p.idx ? __builtin_amdgcn_readfirstlane(norm_index(p.idx[c], p.n_pool)) : c;
+        src0[r] = p.src + (int64_t)i0 * p.nvp;
       }
+      dstp[r] = p.outp + (int64_t)c * p.nvp;
+      dstb[r] = OBS ? p.outb + (int64_t)c * p.pitch : nullptr;
     }
-  };
-  auto trip = [&](int base, const Words &w, Words &next) {
-    const int v = base + lane;
-    const bool has = v < p.nvec;
-    const int vv = v < last ? v : last;
-#if defined(BH_GEBV_F64)
-    double2 ef[TT][4];
-#pragma unroll
-    for (int q = 0; q < TT; ++q) {
-      const double2 *ep = reinterpret_cast<const double2 *>(p.eff + (int64_t)q * p.effPitch + 8 * (int64_t)vv);
-      ef[q][0] = ep[0];
-      ef[q][1] = ep[1];
-      ef[q][2] = ep[2];
-      ef[q][3] = ep[3];
-    }
-#else
-    uint4 dg[TT][3];
-#pragma unroll
-    for (int q = 0; q < TT; ++q) {
-#if defined(BH_DIG_INTERLEAVED)  // tuning experiments only: digits of a vector side by side (lane stride 48 B)
-      const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
-      dg[q][0] = dp[0];
-      dg[q][1] = dp[1];
-      dg[q][2] = dp[2];
-#else  // one plane per digit: a wave's load is 1 KB contiguous
-      const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vv;
-      dg[q][0] = dp[0];
-      dg[q][1] = dp[p.nvec];
-      dg[q][2] = dp[2 * (int64_t)p.nvec];
-#endif
-    }
-#endif
-    load_words(base + 64, next);
-    uint4 oo[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      uint32_t o = w.a[r];
-      if constexpr (MODE == MODE_CROSS) o = cross16(w.a[r], w.b[r], w.z[r]);
-      dstp[r][vv] = (uint16_t)o;
-      oo[r] = expand_vector(o);
-      if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16 * (int64_t)vv) = oo[r];
-    }
-    if (has) {  // a lane that redid the last vector must not count it twice
-#if defined(BH_GEBV_F64)
-#pragma unroll
-      for (int q = 0; q < TT; ++q) {
-        const double e[8] = {ef[q][0].x, ef[q][0].y, ef[q][1].x, ef[q][1].y, ef[q][2].x, ef[q][2].y, ef[q][3].x, ef[q][3].y};
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const Dosage8 d = dosages(oo[r]);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) acc[r][q] = fma(d.d[k], e[k], acc[r][q]);
-        }
-      }
-#else
-      typedef short short2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t w[4] = {oo[r].x, oo[r].y, oo[r].z, oo[r].w};
-        uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pr[k] = (w[k] + (w[k] >> 8)) & 0x00FF00FFu;
-#pragma unroll
-        for (int q = 0; q < TT; ++q)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const uint32_t dd[4] = {dg[q][j].x, dg[q][j].y, dg[q][j].z, dg[q][j].w};
-            int a = acc[r][q][j];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
-            acc[r][q][j] = a;
-          }
-      }
-#endif
-    }
-  };
-  Words wa, wb;
-  load_words(0, wa);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending (row_role_pipelined)
-  for (int base = 0; base < p.nvec; base += 128) {  // two trips per turn, no branch between them
-    trip(base, wa, wb);
-    trip(base + 64, wb, wa);
-  }
-  if (p.nvec + lane < p.nvp) {  // padding words: markers beyond M, up to the next multiple of 64
-#pragma unroll
-    for (int r = 0; r < R; ++r) dstp[r][p.nvec + lane] = 0;
-  }
+    auto word_at = [](const uint16_t *base, uint32_t v) -> uint32_t {
+      return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + 2u * v);
+    };
 
-#if defined(BH_GEBV_F64)
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      double s = acc[r][t];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      acc[r][t] = s;
-    }
-  if (lane == 0) {
+    // GEBV in exact fixed point: the effects are round(e * 2^s_t) cut into three balanced base-65536
+    // digits (as gebv_mfma.h cuts them into six base-256 ones), the dosages of a marker pair are the
+    // two int16 halves of (w + (w >> 8)) & 0x00FF00FF, and a v_dot2_i32_i16 per pair and digit replaces
+    // eight conversions and eight f64 FMAs per vector.  |digit| <= 2^15 and dosage <= 2, so a lane's
+    // int32 sums stay below 2^31 for rows of up to 2^21 markers (bh_max_markers() is 2^18).
+    int acc[R][NT][3];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (live[r]) {
 #pragma unroll
-        for (int t = 0; t < TT; ++t) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[r][t][j] = 0;
+
+    const int last = p.nvec - 1;
+    // VPT vectors per lane and trip (64 apart: every load and store of the wave stays contiguous): with few
+    // waves per row stream the bytes in flight have to come from each wave
+    struct Words {
+      uint32_t a[VPT][R], b[VPT][R], z[VPT][R];
+    };
+    auto load_words = [&](int base, Words &w) {
+#pragma unroll
+      for (int u = 0; u < VPT; ++u) {
+        int v = base + 64 * u + lane;
+        v = v < last ? v : last;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          w.a[u][r] = word_at(src0[r], (uint32_t)v);
+          if constexpr (MODE == MODE_CROSS) {
+            w.b[u][r] = word_at(src1[r], (uint32_t)v);
+            w.z[u][r] = word_at(Z16[r], (uint32_t)v);
+          } else {
+            w.b[u][r] = 0;
+            w.z[u][r] = 0;
+          }
+        }
       }
-  }
-#else
+    };
+    auto trip = [&](int base, const Words &w, Words &next) {
+      const int v = base + lane;
+      const bool has = v < p.nvec;
+      const int vv = v < last ? v : last;
+      uint4 dg[NT][3];
+      if constexpr (TT > 0) {
 #pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      // digits recombined in int64 per lane, then summed over the wave: exact, order-free
-      long long s = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0 && live[r]) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)((double)s * p.scale[p.t0 + t]);
-    }
+        for (int q = 0; q < TT; ++q) {
+#if defined(BH_DIG_INTERLEAVED)  // tuning experiments only: digits of a vector side by side (lane stride 48 B)
+          const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
+          dg[q][0] = dp[0];
+          dg[q][1] = dp[1];
+          dg[q][2] = dp[2];
+#else  // one plane per digit: a wave's load is 1 KB contiguous
+          const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vv;
+          dg[q][0] = dp[0];
+          dg[q][1] = dp[p.nvec];
+          dg[q][2] = dp[2 * (int64_t)p.nvec];
 #endif
+        }
+      }
+      load_words(base + 64 * VPT, next);
+      uint4 oo[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+          const int vu = v + 64 * u < last ? v + 64 * u : last;
+          uint32_t o = w.a[u][r];
+          if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
+          *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
+          oo[r] = expand_vector(o);
+          if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo[r];
+        }
+      if constexpr (TT > 0) {
+        if (has) {  // a lane that redid the last vector must not count it twice
+          typedef short short2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t ww[4] = {oo[r].x, oo[r].y, oo[r].z, oo[r].w};
+            uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
+#pragma unroll
+            for (int q = 0; q < TT; ++q)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const uint32_t dd[4] = {dg[q][j].x, dg[q][j].y, dg[q][j].z, dg[q][j].w};
+                int a = acc[r][q][j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
+                acc[r][q][j] = a;
+              }
+          }
+        }
+      }
+    };
+    Words wa, wb;
+    load_words(0, wa);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending (row_role_pipelined)
+    for (int base = 0; base < p.nvec; base += 128 * VPT) {  // two trips per turn, no branch between them
+      trip(base, wa, wb);
+      trip(base + 64 * VPT, wb, wa);
+    }
+    if (p.nvec + lane < p.nvp) {  // padding words: markers beyond M, up to the next multiple of 64
+#pragma unroll
+      for (int r = 0; r < R; ++r) dstp[r][p.nvec + lane] = 0;
+    }
+
+    if constexpr (TT > 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          // digits recombined in int64 per lane, then summed over the wave: exact, order-free
+          long long sum = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+          if (lane == 0 && live[r]) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)((double)sum * p.scale[p.t0 + t]);
+        }
+    }
+  }
 }
 
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
-  const int wave = (int)(threadIdx.x >> 6);
-  if constexpr (TT == 1 || TT == 2) {
-    // packed rows out, GEBV wanted (reset's founder gather, a cross without run-ahead): the
-    // pipelined stream
-    if (p.outp) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
+  if constexpr (TT <= 2) {
+    // packed rows out (reset's founder gather, a cross without run-ahead): the pipelined stream; without
+    // GEBV only where the host asks for it (p.seq > 1: long rows in turns)
+    if (p.outp && (TT > 0 || p.seq > 1)) {
+      constexpr int V = TT == 0 ? kLongRowVectors : 1;
       if (p.outb)
-        packed_stream_role<TT, MODE, R, true>(p, (int)blockIdx.x, wave);
+        packed_stream_role<TT, MODE, R, true, V>(p, (int)blockIdx.x, wave);
       else
-        packed_stream_role<TT, MODE, R, false>(p, (int)blockIdx.x, wave);
+        packed_stream_role<TT, MODE, R, false, V>(p, (int)blockIdx.x, wave);
       return;
     }
   }
@@ -394,7 +380,7 @@ template <int TT, int MW, int R>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if constexpr (MW == 4) {
     if (threadIdx.x == 0) {
       counter = 0;
@@ -410,12 +396,15 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) {
 #if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
-      if constexpr ((TT == 1 || TT == 2) && MW == 4) {
-        if (rp.outb)
-          packed_stream_role<TT, MODE_CROSS, R, true>(rp, (int)blockIdx.x, wave);
-        else
-          packed_stream_role<TT, MODE_CROSS, R, false>(rp, (int)blockIdx.x, wave);
-        return;
+      if constexpr (TT <= 2 && MW == 4) {
+        if (TT > 0 || rp.seq > 1) {
+          constexpr int V = TT == 0 ? kLongRowVectors : 1;
+          if (rp.outb)
+            packed_stream_role<TT, MODE_CROSS, R, true, V>(rp, (int)blockIdx.x, wave);
+          else
+            packed_stream_role<TT, MODE_CROSS, R, false, V>(rp, (int)blockIdx.x, wave);
+          return;
+        }
       }
 #endif
       packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave);

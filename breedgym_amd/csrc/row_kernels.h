@@ -178,7 +178,10 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   // four-wave groups run next to row waves at the default priority (few keyed crosses, the launch
   // is bound by the streaming): one step above them the mask role is out of the way sooner --
   // 1-5 % on most shapes, 11 % at 2200 x 16k markers, -2 % on one (profiles/r01_ab_mask_priority.txt)
-  if constexpr (SYNC == SYNC_COUNTER) __builtin_amdgcn_s_setprio(1);
+#ifndef BH_MASK_PRIO  // tuning experiments only
+#define BH_MASK_PRIO 1
+#endif
+  if constexpr (SYNC == SYNC_COUNTER && BH_MASK_PRIO > 0) __builtin_amdgcn_s_setprio(BH_MASK_PRIO);
   uint64_t *S = reinterpret_cast<uint64_t *>(lds_raw + (size_t)grp * p.group_lds);  // [nwh + 1][4]
 
   // ---- gamete keys: keys = split(sim_key, nkeys); gamete (c, q) owns keys[1 + 2c + q] (double
@@ -242,32 +245,38 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     }                                                                                                               \
   }
 
+#if defined(BH_ABLATE_MASK_NOLOAD)  // timing experiments only: the mask role without its table loads (wrong masks)
+#define BH_TLOAD(r_, v_, s_) ((v_) + (s_))
+#else
+#define BH_TLOAD(r_, v_, s_) __builtin_amdgcn_raw_buffer_load_b32(r_, v_, s_, 0)
+#endif
   {
     int t = wv;
     uint32_t j = (uint32_t)wv * 64u + lane;
     uint32_t soff = (uint32_t)wv * 256u;
     constexpr uint32_t STEP = 256u * WAVES;
-    uint32_t tA0 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff, 0);
-    uint32_t tB0 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff, 0);
-    uint32_t cB0 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff, 0);
-    uint32_t tA1 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + STEP, 0);
-    uint32_t tB1 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + STEP, 0);
-    uint32_t cB1 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff + STEP, 0);
+    uint32_t tA0 = BH_TLOAD(rA, voff, soff);
+    uint32_t tB0 = BH_TLOAD(rB, voff, soff);
+    uint32_t cB0 = BH_TLOAD(rC, voff, soff);
+    uint32_t tA1 = BH_TLOAD(rA, voff, soff + STEP);
+    uint32_t tB1 = BH_TLOAD(rB, voff, soff + STEP);
+    uint32_t cB1 = BH_TLOAD(rC, voff, soff + STEP);
     while (t < p.nwh) {
       BH_TRIP(t, j, tA0, tB0, cB0)
-      tA0 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + 2u * STEP, 0);
-      tB0 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + 2u * STEP, 0);
-      cB0 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff + 2u * STEP, 0);
+      tA0 = BH_TLOAD(rA, voff, soff + 2u * STEP);
+      tB0 = BH_TLOAD(rB, voff, soff + 2u * STEP);
+      cB0 = BH_TLOAD(rC, voff, soff + 2u * STEP);
       if (t + WAVES < p.nwh) BH_TRIP(t + WAVES, j + 64u * WAVES, tA1, tB1, cB1)
-      tA1 = __builtin_amdgcn_raw_buffer_load_b32(rA, voff, soff + 3u * STEP, 0);
-      tB1 = __builtin_amdgcn_raw_buffer_load_b32(rB, voff, soff + 3u * STEP, 0);
-      cB1 = __builtin_amdgcn_raw_buffer_load_b32(rC, voff, soff + 3u * STEP, 0);
+      tA1 = BH_TLOAD(rA, voff, soff + 3u * STEP);
+      tB1 = BH_TLOAD(rB, voff, soff + 3u * STEP);
+      cB1 = BH_TLOAD(rC, voff, soff + 3u * STEP);
       t += 2 * WAVES;
       j += 128u * WAVES;
       soff += 2u * STEP;
     }
   }
 #undef BH_TRIP
+#undef BH_TLOAD
   if (tid == 0) {
     S[4 * p.nwh + 1] = 0;  // the word behind the last B words (funnel shifts read one ahead)
     S[4 * p.nwh + 3] = 0;
@@ -660,13 +669,13 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
 template <int WAVES>
 __global__ __launch_bounds__(256) void mask_kernel(const MaskParams p) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
-  mask_role<WAVES, WAVES == 1 ? SYNC_WAVE : SYNC_BLOCK>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), lds_raw, nullptr);
+  mask_role<WAVES, WAVES == 1 ? SYNC_WAVE : SYNC_BLOCK>(p, (int)blockIdx.x, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lds_raw, nullptr);
 }
 
 template <int WAVES, int TT, int MODE, int R, bool LONG>
 __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
   __shared__ double red[4 * (TT > 0 ? TT : 1)];
-  row_role<WAVES, TT, MODE, R, LONG>(p, (int)blockIdx.x, (int)(threadIdx.x >> 6), red);
+  row_role<WAVES, TT, MODE, R, LONG>(p, (int)blockIdx.x, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), red);
 }
 
 // One launch, two roles, for rows that one wave handles.  A workgroup is 8 waves: waves 0-3
@@ -682,7 +691,7 @@ template <int TT, int MW, int R, bool LONG>
 __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if constexpr (MW == 4) {
     if (threadIdx.x == 0) {
       counter = 0;
