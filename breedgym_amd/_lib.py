@@ -81,7 +81,7 @@ SIGNATURES = {
     "bh_memcpy_d2h": (_int, [_vp, _vp, _vp, _i64]),
     "bh_upload_population": (_int, [_vp, _vp, _i64, _vp, _int]),
     "bh_download_population": (_int, [_vp, _vp, _i64, _vp]),
-    "bh_cross": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp]),
+    "bh_cross": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp]),
     "bh_set_mask_prefetch": (_int, [_vp, _int]),
     "bh_gather": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "bh_gebv": (_int, [_vp, _vp, _i64, _vp]),
@@ -91,7 +91,7 @@ SIGNATURES = {
     "bh_optimal_haploid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "bh_packed_pitch": (_i64, [_vp]),
     "bh_pack": (_int, [_vp, _vp, _i64, _vp]),
-    "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp]),
+    "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp, _vp]),
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
     "bh_key_split": (_int, [_u32p, _i64, _u32p]),

@@ -87,6 +87,9 @@ struct bh_ctx {
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};
   int64_t cand_cap = 0;
+  // reward chaining (bh_cross*): the buffer the last launch left holding -inf, ready to take atomic maxima
+  const float *primed_reward = nullptr;
+  int64_t primed_envs = 0;
   bool big_lds_set = false;
   bool select_lds_set = false;
 };
@@ -839,7 +842,8 @@ int bh_download_population(bh_ctx *c, const uint8_t *d_src, int64_t rows, uint8_
 // d_out_bytes is the byte-layout offspring (required unless packed, optional when packed).
 static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_pool, int64_t n_envs,
                       int64_t pool_rows, const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
-                      uint8_t *d_out_bytes, uint16_t *d_out_packed, float *d_gebv, float *d_reward) {
+                      uint8_t *d_out_bytes, uint16_t *d_out_packed, float *d_gebv, float *d_reward,
+                      float *d_reward_next) {
   if (int rc = check_ctx(c)) return rc;
   if (!sim_key) return fail(BH_ERR_BAD_ARG, "%s: null sim_key", who);
   if (n_envs < 0 || n_out < 0 || pool_rows < 0) return fail(BH_ERR_BAD_ARG, "%s: negative size", who);
@@ -904,6 +908,12 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh);
     }
     const bool wide = rows >= 4096;  // else one row per wave: more waves in flight
+    // the per-env maximum comes out of the same launch when the GEBV does: every row wave notes its value
+    // with an atomic max into a buffer that holds -inf -- left so by the launch before (d_reward_next of that
+    // call), or set so now
+    const bool reward_in_launch = d_reward && fused;
+    if (reward_in_launch && !(c->primed_reward == d_reward && c->primed_envs == n_envs))
+      BH_HIP(hipMemsetD32Async(d_reward, (int)0xFF800000u, (size_t)n_envs, c->stream));
     int rc;
     if (packed) {
       bh::PackedParams p = packed_params(c);
@@ -918,6 +928,9 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.n_rows = (int32_t)rows;
       p.rng_shared = shared;
       p.tcount = tcount;
+      p.reward = reward_in_launch ? d_reward : nullptr;
+      p.reward_next = d_reward_next;
+      p.n_envs = (int32_t)n_envs;
       const int turns = (tcount == 0 && (!run_ahead || mw == 4)) ? long_row_turns(c, rows) : 0;
       p.seq = turns;
       if (run_ahead) {
@@ -947,6 +960,9 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.rng_shared = shared;
       p.t0 = 0;
       p.tcount = tcount;
+      p.reward = reward_in_launch ? d_reward : nullptr;
+      p.reward_next = d_reward_next;
+      p.n_envs = (int32_t)n_envs;
       if (run_ahead) {
         if (mw == 1)
           rc = wide ? launch_cross_mw<1, kRowsPerWaveCross>(c, p, mp, tt_for(tcount))
@@ -975,10 +991,15 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
         rc = gebv_chunks(c, d_out_bytes, rows, d_gebv, 0);
       if (rc) return rc;
     }
-    // the reward of vec_env.py:97: a 2 us reduction kernel behind the cross launch (an in-launch
-    // arrival protocol with atomics was measured slower: +6.6 us against +2.2 us)
-    if (d_reward)
+    // the reward of vec_env.py:97 where the GEBV came from a pass of its own: a reduction kernel behind it
+    if (d_reward && !reward_in_launch)
       if (int rc2 = bh_reward_max(c, d_gebv, n_envs, n_out * c->T, d_reward)) return rc2;
+    c->primed_reward = d_reward_next;
+    c->primed_envs = d_reward_next ? n_envs : 0;
+  } else if (d_reward_next && n_envs > 0) {
+    BH_HIP(hipMemsetD32Async(d_reward_next, (int)0xFF800000u, (size_t)n_envs, c->stream));
+    c->primed_reward = d_reward_next;
+    c->primed_envs = n_envs;
   }
   sim_key[0] = nk.x;
   sim_key[1] = nk.y;
@@ -986,16 +1007,17 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
 }
 
 int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
-             int64_t n_out, uint32_t sim_key[2], int rng_mode, uint8_t *d_out, float *d_gebv, float *d_reward) {
+             int64_t n_out, uint32_t sim_key[2], int rng_mode, uint8_t *d_out, float *d_gebv, float *d_reward,
+             float *d_reward_next) {
   return cross_impl(c, "bh_cross", false, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode, d_out, nullptr,
-                    d_gebv, d_reward);
+                    d_gebv, d_reward, d_reward_next);
 }
 
 int bh_cross_packed(bh_ctx *c, const uint16_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
                     int64_t n_out, uint32_t sim_key[2], int rng_mode, uint16_t *d_out_packed, uint8_t *d_out_bytes,
-                    float *d_gebv, float *d_reward) {
+                    float *d_gebv, float *d_reward, float *d_reward_next) {
   return cross_impl(c, "bh_cross_packed", true, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode,
-                    d_out_bytes, d_out_packed, d_gebv, d_reward);
+                    d_out_bytes, d_out_packed, d_gebv, d_reward, d_reward_next);
 }
 
 int64_t bh_packed_pitch(const bh_ctx *c) { return c ? (int64_t)16 * c->nw : 0; }

@@ -44,6 +44,9 @@ struct PackedParams {
   int32_t T, t0, tcount;
   int32_t rng_shared;
   int32_t seq;  // row groups a wave of packed_stream_role streams one after the other (>= 1)
+  float *reward;       // cross: (n_envs) max GEBV per env, holding -inf on entry (reward_note), or null
+  float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
+  int32_t n_envs;
 };
 
 // dword k of byte-layout vector v from its packed word: bits 4k .. 4k+3 are its four bytes; the
@@ -71,7 +74,8 @@ __device__ __forceinline__ uint32_t cross16(uint32_t p0, uint32_t p1, uint32_t z
 // next trips' words ahead of the current trip's stores (software pipelining) was measured -- it costs
 // registers the mask role next door needs more than the row role needs the overlap.
 template <int TT, int MODE, int R, int PRIO = 3>
-__device__ __forceinline__ void packed_row_role(const PackedParams &p, const int block, const int wave) {
+__device__ __forceinline__ void packed_row_role(const PackedParams &p, const int block, const int wave,
+                                                RewardLds *rw = nullptr) {
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   constexpr int NT = TT > 0 ? TT : 1;
   const int lane = threadIdx.x & 63;
@@ -167,13 +171,25 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
         acc[r][t] = s;
       }
     if (lane == 0) {
+      int env0 = 0, expected = 0;
+      if constexpr (MODE == MODE_CROSS)
+        if (p.reward) reward_wg_layout(block, p.n_blocks, R, p.n_rows, p.n_out, env0, expected);
 #pragma unroll
       for (int r = 0; r < R; ++r)
         if (live[r]) {
+          float best = -INFINITY;
 #pragma unroll
           for (int t = 0; t < TT; ++t)
-            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t];
+            if (t < p.tcount) {
+              const float g = (float)acc[r][t];
+              p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
+              best = g != g ? best : fmaxf(best, g);
+            }
+          if constexpr (MODE == MODE_CROSS)
+            if (p.reward) reward_row(rw, p.reward, env0, c0 + r, p.n_out, best);
         }
+      if constexpr (MODE == MODE_CROSS)
+        if (p.reward) reward_wave_done(rw, p.reward, env0, expected);
     }
   }
 }
@@ -189,7 +205,8 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 // fewer row streams the chip writes at a time the better the DRAM pages are used -- 8192 streams of
 // 100k markers store at 2.4 TB/s, 2048 at 7.7 (profiles/r01_exp_long_rows_streams.txt).
 template <int TT, int MODE, int R, bool OBS, int VPT = 1>
-__device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave) {
+__device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave,
+                                                   RewardLds *rw = nullptr) {
   static_assert(TT >= 0 && TT <= 2, "effects are held in registers across the trip");
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   static_assert(VPT == 1 || TT == 0, "several vectors per lane and trip only without GEBV in the stream");
@@ -342,6 +359,10 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     }
 
     if constexpr (TT > 0) {
+      // (with GEBV in the stream a wave has one row group: seq == 1)
+      int env0 = 0, expected = 0;
+      if constexpr (MODE == MODE_CROSS)
+        if (p.reward) reward_wg_layout(block, p.n_blocks, R, p.n_rows, p.n_out, env0, expected);
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -350,14 +371,27 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           long long sum = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
 #pragma unroll
           for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-          if (lane == 0 && live[r]) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)((double)sum * p.scale[p.t0 + t]);
+          if (lane == 0 && live[r]) {
+            const float g = (float)((double)sum * p.scale[p.t0 + t]);
+            p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
+            if constexpr (MODE == MODE_CROSS)
+              if (p.reward) reward_row(rw, p.reward, env0, c0 + r, p.n_out, g);
+          }
         }
+      if constexpr (MODE == MODE_CROSS)
+        if (lane == 0 && p.reward) reward_wave_done(rw, p.reward, env0, expected);
     }
   }
 }
 
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
+  __shared__ RewardLds rwl;
+  prime_next_reward(p.reward_next, p.n_envs);
+  if (p.reward) {
+    if (threadIdx.x == 0) reward_lds_init(&rwl);
+    __syncthreads();
+  }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if constexpr (TT <= 2) {
     // packed rows out (reset's founder gather, a cross without run-ahead): the pipelined stream; without
@@ -365,13 +399,13 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
     if (p.outp && (TT > 0 || p.seq > 1)) {
       constexpr int V = TT == 0 ? kLongRowVectors : 1;
       if (p.outb)
-        packed_stream_role<TT, MODE, R, true, V>(p, (int)blockIdx.x, wave);
+        packed_stream_role<TT, MODE, R, true, V>(p, (int)blockIdx.x, wave, &rwl);
       else
-        packed_stream_role<TT, MODE, R, false, V>(p, (int)blockIdx.x, wave);
+        packed_stream_role<TT, MODE, R, false, V>(p, (int)blockIdx.x, wave, &rwl);
       return;
     }
   }
-  packed_row_role<TT, MODE, R>(p, (int)blockIdx.x, wave);
+  packed_row_role<TT, MODE, R>(p, (int)blockIdx.x, wave, &rwl);
 }
 
 // cross_kernel (row_kernels.h) with the packed row role: waves 0-3 stream generation g, waves 4-7
@@ -380,11 +414,14 @@ template <int TT, int MW, int R>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
+  __shared__ RewardLds rwl;
+  prime_next_reward(rp.reward_next, rp.n_envs);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
-  if constexpr (MW == 4) {
+  if (MW == 4 || rp.reward) {  // uniform: the whole workgroup meets here or nowhere
     if (threadIdx.x == 0) {
       counter = 0;
       done = 0;
+      reward_lds_init(&rwl);
     }
     __syncthreads();
   }
@@ -400,14 +437,14 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
         if (TT > 0 || rp.seq > 1) {
           constexpr int V = TT == 0 ? kLongRowVectors : 1;
           if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true, V>(rp, (int)blockIdx.x, wave);
+            packed_stream_role<TT, MODE_CROSS, R, true, V>(rp, (int)blockIdx.x, wave, &rwl);
           else
-            packed_stream_role<TT, MODE_CROSS, R, false, V>(rp, (int)blockIdx.x, wave);
+            packed_stream_role<TT, MODE_CROSS, R, false, V>(rp, (int)blockIdx.x, wave, &rwl);
           return;
         }
       }
 #endif
-      packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave);
+      packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, &rwl);
     }
   } else if constexpr (MW == 1) {
     if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);

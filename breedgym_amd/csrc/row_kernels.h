@@ -52,6 +52,8 @@ struct MaskParams {
   int32_t dh;           // 1: both gametes of cross c use keys[1 + c] (one gamete, doubled)
 };
 
+__device__ __forceinline__ int xcd_row(int b, int n);
+
 struct RowParams {
   const uint8_t *src;  // cross: (E, n_pool, pitch) pool; gather: (n_pool, pitch); gebv: (rows, pitch)
   uint8_t *out;        // (rows, pitch) or null (gebv)
@@ -70,7 +72,79 @@ struct RowParams {
   int32_t n_blocks;       // workgroups with row waves = ceil(n_rows / (R * 4 / WAVES))
   int32_t T, t0, tcount;  // GEBV row stride, first trait and trait count of this launch
   int32_t rng_shared;     // 1: mask row = env-local cross index (all envs share the masks)
+  float *reward;          // cross: (n_envs) max GEBV per env, holding -inf on entry (reward_note), or null
+  float *reward_next;     // (n_envs) set to -inf by this launch for a later one, or null
+  int32_t n_envs;
 };
+
+// reward[env] = max(reward[env], v) for a buffer that held -inf before the launch: the sign decides between
+// a signed max and an unsigned min on the same bits (non-negative floats order like ints, negative ones in
+// reverse like uints).  Device scope, no return value, no ordering needed: max commutes.
+__device__ __forceinline__ void reward_note(float *reward, int env, float v) {
+  if (v != v) return;
+  const unsigned u = __float_as_uint(v);
+  if (u >> 31)
+    atomicMin(reinterpret_cast<unsigned *>(reward) + env, u);
+  else
+    atomicMax(reinterpret_cast<int *>(reward) + env, (int)u);
+}
+
+// Same-address device-scope atomics are served one after the other at the memory side (~170 ns each: 256
+// per env and launch cost 40 us at 16 x 256 crosses), so the row waves of a workgroup first meet in LDS --
+// maxima of order-preserving keys, then an arrival count -- and the last one notes the workgroup's value:
+// one global atomic per workgroup and env.  A workgroup's rows lie in at most two envs whenever an env has
+// at least as many rows as the workgroup; a row of a third env goes to memory directly.
+struct RewardLds {
+  unsigned count;
+  unsigned best[2];  // order-preserving keys of the maxima of the workgroup's first and second env; 0 = none
+};
+__device__ __forceinline__ unsigned reward_key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float reward_unkey(unsigned k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__device__ __forceinline__ void reward_lds_init(RewardLds *rw) {  // thread 0, before a workgroup barrier
+  rw->count = 0;
+  rw->best[0] = 0;
+  rw->best[1] = 0;
+}
+// one lane per wave: `row`'s value
+__device__ __forceinline__ void reward_row(RewardLds *rw, float *reward, int env0, int row, int n_out, float v) {
+  if (v != v) return;
+  const int env = row / n_out;
+  if (rw && env - env0 < 2)
+    atomicMax(&rw->best[env - env0], reward_key(v));
+  else
+    reward_note(reward, env, v);
+}
+// one lane per wave, after its reward_row calls; `expected` = row waves of this workgroup that have rows
+__device__ __forceinline__ void reward_wave_done(RewardLds *rw, float *reward, int env0, int expected) {
+  if (!rw) return;
+  if (atomicAdd(&rw->count, 1u) + 1u == (unsigned)expected) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned k = atomicMax(&rw->best[s], 0u);
+      if (k) reward_note(reward, env0 + s, reward_unkey(k));
+    }
+  }
+}
+// first row of a workgroup of four row waves with `per_wave` rows each, the env it lies in, and how many of
+// its waves have rows
+__device__ __forceinline__ void reward_wg_layout(int block, int n_blocks, int per_wave, int n_rows, int n_out,
+                                                 int &env0, int &expected) {
+  const int first = xcd_row(block, n_blocks) * 4 * per_wave;
+  env0 = first / n_out;
+  const int left = n_rows - first;
+  expected = left <= 0 ? 0 : (left >= 4 * per_wave ? 4 : (left + per_wave - 1) / per_wave);
+}
+
+// what the first workgroup of every launch does for the launch after it
+__device__ __forceinline__ void prime_next_reward(float *reward_next, int n_envs) {
+  if (reward_next && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_envs; i += blockDim.x) reward_next[i] = -INFINITY;
+}
 
 // Blocks b, b+8, b+16.. are dealt to the same XCD (round-robin dispatch).  Hand every XCD a
 // contiguous run of rows so that the crosses of one env, which gather from the same parent
@@ -372,7 +446,8 @@ __device__ __forceinline__ Dosage8 dosages(const uint4 o) {
 // bytes out of L2).  R > 1 only with WAVES == 1.
 // LONG rows (HBM-resident sets) want more loads in flight: two vectors per row and trip.
 template <int WAVES, int TT, int MODE, int R, bool LONG, int PRIO = 3>
-__device__ __forceinline__ void row_role(const RowParams &p, const int block, const int wave, double *red) {
+__device__ __forceinline__ void row_role(const RowParams &p, const int block, const int wave, double *red,
+                                         RewardLds *rw = nullptr) {
   static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or the whole workgroup");
   static_assert(R == 1 || WAVES == 1, "several rows per group only for one-wave groups");
   constexpr int GROUPS = 4 / WAVES;
@@ -522,13 +597,25 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
         }
     }
     if (tid == 0) {
+      int env0 = 0, expected = 0;
+      if constexpr (MODE == MODE_CROSS)
+        if (p.reward && WAVES == 1) reward_wg_layout(block, p.n_blocks, R, p.n_rows, p.n_out, env0, expected);
 #pragma unroll
       for (int r = 0; r < R; ++r)
         if (live[r]) {
+          float best = -INFINITY;
 #pragma unroll
           for (int t = 0; t < TT; ++t)
-            if (t < p.tcount) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)acc[r][t][0];
+            if (t < p.tcount) {
+              const float g = (float)acc[r][t][0];
+              p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
+              best = g != g ? best : fmaxf(best, g);
+            }
+          if constexpr (MODE == MODE_CROSS)
+            if (p.reward) reward_row(WAVES == 1 ? rw : nullptr, p.reward, env0, c0 + r, p.n_out, best);
         }
+      if constexpr (MODE == MODE_CROSS)
+        if (p.reward && WAVES == 1) reward_wave_done(rw, p.reward, env0, expected);
     }
   }
 }
@@ -542,7 +629,8 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
 // body is branch-free so that the compiler's counter model stays exact: lanes past the end of the row
 // redo the last vector, dead row slots redo row c0 -- the same bytes stored twice.
 template <int TT, int R>
-__device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int block, const int wave) {
+__device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int block, const int wave,
+                                                   RewardLds *rw = nullptr) {
   static_assert(TT == 1 || TT == 2, "effects are held in registers across the trip");
   const int lane = threadIdx.x & 63;
   const int c0 = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R);
@@ -655,6 +743,8 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
     trip(base + 64, wb, wa);
   }
 
+  int env0 = 0, expected = 0;
+  if (p.reward) reward_wg_layout(block, p.n_blocks, R, p.n_rows, p.n_out, env0, expected);
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -662,8 +752,13 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
       long long s = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0 && live[r]) p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = (float)((double)s * p.scale[p.t0 + t]);
+      if (lane == 0 && live[r]) {
+        const float g = (float)((double)s * p.scale[p.t0 + t]);
+        p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
+        if (p.reward) reward_row(rw, p.reward, env0, c0 + r, p.n_out, g);
+      }
     }
+  if (lane == 0 && p.reward) reward_wave_done(rw, p.reward, env0, expected);
 }
 
 template <int WAVES>
@@ -675,7 +770,14 @@ __global__ __launch_bounds__(256) void mask_kernel(const MaskParams p) {
 template <int WAVES, int TT, int MODE, int R, bool LONG>
 __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
   __shared__ double red[4 * (TT > 0 ? TT : 1)];
-  row_role<WAVES, TT, MODE, R, LONG>(p, (int)blockIdx.x, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), red);
+  __shared__ RewardLds rwl;
+  prime_next_reward(p.reward_next, p.n_envs);
+  if (p.reward) {
+    if (threadIdx.x == 0) reward_lds_init(&rwl);
+    __syncthreads();
+  }
+  row_role<WAVES, TT, MODE, R, LONG>(p, (int)blockIdx.x, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), red,
+                                     &rwl);
 }
 
 // One launch, two roles, for rows that one wave handles.  A workgroup is 8 waves: waves 0-3
@@ -691,11 +793,14 @@ template <int TT, int MW, int R, bool LONG>
 __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const MaskParams mp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
+  __shared__ RewardLds rwl;
+  prime_next_reward(rp.reward_next, rp.n_envs);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
-  if constexpr (MW == 4) {
+  if (MW == 4 || rp.reward) {  // uniform: the whole workgroup meets here or nowhere
     if (threadIdx.x == 0) {
       counter = 0;
       done = 0;
+      reward_lds_init(&rwl);
     }
     __syncthreads();
   }
@@ -708,10 +813,10 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
     if ((int)blockIdx.x < rp.n_blocks) {
 #if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr ((TT == 1 || TT == 2) && !LONG && MW == 4)
-        row_role_pipelined<TT, R>(rp, (int)blockIdx.x, wave);
+        row_role_pipelined<TT, R>(rp, (int)blockIdx.x, wave, &rwl);
       else
 #endif
-        row_role<1, TT, MODE_CROSS, R, LONG, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, nullptr);
+        row_role<1, TT, MODE_CROSS, R, LONG, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, nullptr, &rwl);
     }
   } else if constexpr (MW == 1) {
     if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);

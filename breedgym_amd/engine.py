@@ -217,8 +217,10 @@ class HipEngine(EngineBase):
         return out.view(np.bool_)
 
     # ---- operators ---------------------------------------------------------------------
-    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None) -> None:
-        """Fused gather + meiosis + GEBV (+ per-env max reward) (bh_cross).  ``key`` (uint32[2]) is advanced in place."""
+    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None,
+              reward_next=None) -> None:
+        """Fused gather + meiosis + GEBV (+ per-env max reward) (bh_cross).  ``key`` (uint32[2]) is advanced in place.
+        ``reward_next``: (n_envs,) f32 the launch leaves holding -inf, to be the ``reward`` of the next call."""
         assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
         assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_envs * n_out * 2
         assert pool.shape[0] >= n_envs * pool_rows and out.shape[0] >= n_envs * n_out
@@ -227,7 +229,7 @@ class HipEngine(EngineBase):
             self._L.bh_cross(
                 self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
                 key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out.data_ptr(), _ptr(gebv),
-                _ptr(reward),
+                _ptr(reward), _ptr(reward_next),
             )
         )
 
@@ -253,7 +255,7 @@ class HipEngine(EngineBase):
         return out
 
     def cross_packed(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes=None,
-                     gebv=None, reward=None) -> None:
+                     gebv=None, reward=None, reward_next=None) -> None:
         """``cross`` on a packed pool (bh_cross_packed); ``out_bytes`` also receives the byte-layout offspring."""
         assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
         assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_envs * n_out * 2
@@ -264,7 +266,7 @@ class HipEngine(EngineBase):
             self._L.bh_cross_packed(
                 self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
                 key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out_packed.data_ptr(),
-                _ptr(out_bytes), _ptr(gebv), _ptr(reward),
+                _ptr(out_bytes), _ptr(gebv), _ptr(reward), _ptr(reward_next),
             )
         )
 

@@ -133,19 +133,27 @@ class Simulator:
 
     # ---- the hot path --------------------------------------------------------------------
     def cross_indexed(self, pool_rows_t, n_envs, pool_rows, idx, n_out, out_rows_t, gebv=None,
-                      rng_mode: int = _lib.RNG_SHARED_ENVS, reward=None) -> None:
+                      rng_mode: int = _lib.RNG_SHARED_ENVS, reward=None, reward_next=None) -> None:
         """Fused ``population[actions]`` + ``cross`` + ``GEBV_model`` (+ the per-env max reward);
         advances ``random_key`` once."""
         key = np.ascontiguousarray(self.random_key, np.uint32)
-        self.engine.cross(pool_rows_t, n_envs, pool_rows, idx, n_out, key, rng_mode, out_rows_t, gebv, reward)
+        if reward_next is None:
+            self.engine.cross(pool_rows_t, n_envs, pool_rows, idx, n_out, key, rng_mode, out_rows_t, gebv, reward)
+        else:
+            self.engine.cross(pool_rows_t, n_envs, pool_rows, idx, n_out, key, rng_mode, out_rows_t, gebv, reward,
+                              reward_next)
         self.random_key = key
 
     def cross_indexed_packed(self, pool_packed, n_envs, pool_rows, idx, n_out, out_packed, out_bytes=None, gebv=None,
-                             rng_mode: int = _lib.RNG_SHARED_ENVS, reward=None) -> None:
+                             rng_mode: int = _lib.RNG_SHARED_ENVS, reward=None, reward_next=None) -> None:
         """``cross_indexed`` on bit-plane rows; ``out_bytes`` also receives the byte-layout offspring."""
         key = np.ascontiguousarray(self.random_key, np.uint32)
-        self.engine.cross_packed(pool_packed, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes,
-                                 gebv, reward)
+        if reward_next is None:
+            self.engine.cross_packed(pool_packed, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes,
+                                     gebv, reward)
+        else:
+            self.engine.cross_packed(pool_packed, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes,
+                                     gebv, reward, reward_next)
         self.random_key = key
 
     def cross(self, parents) -> DeviceArray:

@@ -103,6 +103,7 @@ class VecBreedGym(_VectorEnvBase):
         self._prows = None  # storage="bits": (E * n, packed_pitch) bit-plane rows, the state between steps
         self._germ_prows = None
         self._n = None
+        self._rew_primed = None  # (E,) f32 the last cross launch left holding -inf: the next step's reward buffer
         self.step_idx = None
         self.reset_infos = {}
         self.random_key = None
@@ -182,18 +183,30 @@ class VecBreedGym(_VectorEnvBase):
         E, n_pool, n_out = self.num_envs, self._n, idx.shape[1]
         gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
         done = self.step_idx + 1 == self.num_generations
-        # the reward (max GEBV per env, vec_env.py:96-98) comes out of the same launch when it is due
-        rew_dev = eng.empty((E,), torch.float32) if (self.reward_shaping or done) else None
+        # the reward (max GEBV per env, vec_env.py:96-98) comes out of the same launch when it is due: the row
+        # waves note their GEBV with atomic maxima into a buffer the launch before left holding -inf
+        rew_dev = None
+        if self.reward_shaping or done:
+            rew_dev, self._rew_primed = self._rew_primed, None
+            if rew_dev is None or rew_dev.shape[0] != E:
+                rew_dev = eng.empty((E,), torch.float32)  # not primed: the library fills it first
+        # ... and this launch primes the buffer of the next step that has a reward
+        next_idx = 0 if (done and self.autoreset) else self.step_idx + 1
+        rew_next = eng.empty((E,), torch.float32) if (self.reward_shaping or next_idx + 1 == self.num_generations) else None
         if self.storage == "bits":
             outp = eng.empty_packed(E * n_out)
-            out = eng.empty_population(E * n_out) if self.observations == "eager" else None
+            # at the horizon the observation handed out is the next episode's first one (vec_env.py:102-107):
+            # this generation's byte layout would be written for nobody
+            want_obs = self.observations == "eager" and not (done and self.autoreset)
+            out = eng.empty_population(E * n_out) if want_obs else None
             self.simulator.cross_indexed_packed(self._prows, E, n_pool, idx, n_out, outp, out, gebv, self._rng_mode,
-                                                rew_dev)
+                                                rew_dev, rew_next)
             self._adopt(out, n_out, outp)
         else:
             out = eng.empty_population(E * n_out)
-            self.simulator.cross_indexed(self._brows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev)
+            self.simulator.cross_indexed(self._brows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev, rew_next)
             self._adopt(out, n_out)
+        self._rew_primed = rew_next
         self.step_idx += 1
 
         infos = {"GEBV": DeviceArray.wrap(gebv)}

@@ -100,13 +100,20 @@ int bh_download_population(bh_ctx *ctx, const uint8_t *d_src, int64_t rows, uint
  *   d_out   (n_envs, n_out, pitch) u8       offspring; out[e,i,m,p] comes from parent p
  *   d_gebv  (n_envs, n_out, T) f32 or NULL  GEBV of the offspring
  *   d_reward (n_envs) f32 or NULL           max over an env's (n_out, T) GEBV block -- the reward of
- *                                           vec_env.py:97 -- enqueued right behind the cross launch
+ *                                           vec_env.py:97.  Where the GEBV is summed inside the launch
+ *                                           (up to 8 traits, short rows) the row waves note their values
+ *                                           with atomic maxima into this buffer, which must hold -inf
+ *                                           first: it does when it was the d_reward_next of the call
+ *                                           before (and nothing wrote to it since), otherwise the
+ *                                           library fills it first; elsewhere a reduction kernel follows
+ *   d_reward_next (n_envs) f32 or NULL      left holding -inf by this launch, for the caller to pass as
+ *                                           d_reward of its next call (saves that fill)
  *   sim_key host, in/out                    the simulator's threefry key; advanced once
  *                                           per call like `Simulator.cross` does
  * d_out must not alias d_pool. */
 int bh_cross(bh_ctx *ctx, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows,
              const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
-             uint8_t *d_out, float *d_gebv, float *d_reward);
+             uint8_t *d_out, float *d_gebv, float *d_reward, float *d_reward_next);
 
 /* Run-ahead of the crossover masks.  The masks of a generation depend on the key chain and
  * the batch size only, never on the parents, so every bh_cross launch also makes the masks of
@@ -161,7 +168,8 @@ int bh_pack(bh_ctx *ctx, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_pack
  * masks, same offspring as bh_cross on the unpacked pool. */
 int bh_cross_packed(bh_ctx *ctx, const uint16_t *d_pool, int64_t n_envs, int64_t pool_rows,
                     const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
-                    uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv, float *d_reward);
+                    uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv, float *d_reward,
+                    float *d_reward_next);
 /* bh_gather on packed rows (vec_env.py:126-129).  d_idx NULL = rows 0..n_rows-1 in order, which
  * makes this the unpack (d_out_bytes only) and the GEBV of packed rows (d_gebv only).  Any of
  * d_out_packed, d_out_bytes, d_gebv may be NULL. */

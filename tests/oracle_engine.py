@@ -35,8 +35,10 @@ class OracleEngine(EngineBase):
     def download_population(self, rows_t):
         return self._g(rows_t).copy().view(np.bool_)
 
-    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None):
+    def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None, reward_next=None):
         self.calls["cross"] += 1
+        if reward_next is not None:
+            reward_next[:n_envs] = float("-inf")
         p = self._g(pool)[: n_envs * pool_rows].reshape(n_envs, pool_rows, self.n_markers, 2)
         o, newkey = co.cross(p, idx.numpy().reshape(n_envs, n_out, 2), self.r, key, rng_mode)
         key[:] = newkey
@@ -86,9 +88,10 @@ class OracleEngine(EngineBase):
         return out
 
     def cross_packed(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out_packed, out_bytes=None, gebv=None,
-                     reward=None):
+                     reward=None, reward_next=None):
         tmp = self.empty_population(n_envs * n_out)
-        self.cross(self.unpack(pool[: n_envs * pool_rows]), n_envs, pool_rows, idx, n_out, key, rng_mode, tmp, gebv, reward)
+        self.cross(self.unpack(pool[: n_envs * pool_rows]), n_envs, pool_rows, idx, n_out, key, rng_mode, tmp, gebv, reward,
+                   reward_next)
         out_packed[: n_envs * n_out] = self.pack(tmp)
         if out_bytes is not None:
             out_bytes[: n_envs * n_out] = tmp

@@ -28,11 +28,11 @@ int main(int argc, char **argv) {
   bh_pack(ctx, bytes, rows, pool); bh_sync(ctx);
   uint32_t key[2] = {0, 7};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) bh_cross_packed(ctx, pool, E, n, idx, n, key, mode, out, obs ? ob : nullptr, wg ? gebv : nullptr, nullptr);
+  for (int i = 0; i < 5; ++i) bh_cross_packed(ctx, pool, E, n, idx, n, key, mode, out, obs ? ob : nullptr, wg ? gebv : nullptr, nullptr, nullptr);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
   for (int i = 0; i < reps; ++i)
-    bh_cross_packed(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, obs ? ob : nullptr, wg ? gebv : nullptr, nullptr);
+    bh_cross_packed(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, obs ? ob : nullptr, wg ? gebv : nullptr, nullptr, nullptr);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("mode=%d obs=%d gebv=%d M=%lld C=%lld : %.1f us per launch\n", mode, obs, wg, (long long)M, (long long)rows, ms / reps * 1e3);
