@@ -8,13 +8,36 @@ from .engine import DeviceArray, HipEngine, PackedPopulation
 from .simulator import Simulator, TraitModel
 from .vector.vec_env import VecBreedGym
 
-__version__ = "0.1.0"
-__all__ = ["BreedGym", "VecBreedGym", "Simulator", "TraitModel", "HipEngine", "DeviceArray", "PackedPopulation"]
+__version__ = "0.2.0"
+__all__ = ["BreedGym", "VecBreedGym", "Simulator", "TraitModel", "HipEngine", "DeviceArray", "PackedPopulation",
+           "REGISTRY", "make"]
 
-try:  # same ids as the reference, under this package's entry points
+# The six ids the reference registers (breedgym/__init__.py:4-34), under this package's entry points.
+REGISTRY = {
+    "BreedGym": "breedgym_amd.breedgym:BreedGym",
+    "SimplifiedBreedGym": "breedgym_amd.wrappers:SimplifiedBreedGym",
+    "KBestBreedGym": "breedgym_amd.wrappers:KBestBreedGym",
+    "VecBreedGym": "breedgym_amd.vector.vec_env:VecBreedGym",
+    "SelectionScores": "breedgym_amd.vector.vec_wrappers:SelectionScores",
+    "PairScores": "breedgym_amd.vector.vec_wrappers:PairScores",
+}
+
+try:  # with gymnasium installed they are genuine registrations: gym.make("SelectionScores", k=10, ...)
     from gymnasium.envs.registration import register as _register
 
-    _register(id="BreedGym", entry_point="breedgym_amd.breedgym:BreedGym")
-    _register(id="VecBreedGym", entry_point="breedgym_amd.vector.vec_env:VecBreedGym")
+    for _id, _entry in REGISTRY.items():
+        _register(id=_id, entry_point=_entry)
 except ImportError:
     pass
+
+
+def make(id: str, **kwargs):
+    """``gym.make`` for the ids above without gymnasium: ``"breedgym:KBestBreedGym"``-style module prefixes
+    (the reference's tests use both spellings) are accepted."""
+    import importlib
+
+    name = id.split(":")[-1]
+    if name not in REGISTRY:
+        raise KeyError(f"unknown environment id {id!r}; known: {sorted(REGISTRY)}")
+    module, attr = REGISTRY[name].split(":")
+    return getattr(importlib.import_module(module), attr)(**kwargs)

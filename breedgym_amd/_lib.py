@@ -28,6 +28,18 @@ RNG_SHARED_ENVS = 0
 RNG_INDEPENDENT = 1
 RNG_DOUBLE_HAPLOID = 2  # flag: one gamete per row, written to both allele slots
 
+THREEFRY_LAYOUTS = {"original": 0, "partitionable": 1}  # bh_threefry_layout
+
+
+def layout_code(layout) -> int:
+    if isinstance(layout, str):
+        if layout not in THREEFRY_LAYOUTS:
+            raise ValueError(f"threefry_layout must be one of {sorted(THREEFRY_LAYOUTS)}, got {layout!r}")
+        return THREEFRY_LAYOUTS[layout]
+    if layout not in (0, 1):
+        raise ValueError(f"threefry_layout must be 0 or 1, got {layout!r}")
+    return int(layout)
+
 
 class BreedHipError(RuntimeError):
     def __init__(self, code, msg):
@@ -94,9 +106,10 @@ SIGNATURES = {
     "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp, _vp]),
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
-    "bh_key_split": (_int, [_u32p, _i64, _u32p]),
-    "bh_permutation": (_int, [_u32p, _i64, _i32p]),
-    "bh_founders": (_int, [_u32p, _i64, _i64, _i64, _i32p]),
+    "bh_set_threefry_layout": (_int, [_vp, _int]),
+    "bh_key_split": (_int, [_u32p, _i64, _int, _u32p]),
+    "bh_permutation": (_int, [_u32p, _i64, _int, _i32p]),
+    "bh_founders": (_int, [_u32p, _i64, _i64, _i64, _int, _i32p]),
     "bh_founders_device": (_int, [_vp, _u32p, _i64, _i64, _i64, _vp]),
 }
 

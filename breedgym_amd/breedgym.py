@@ -37,6 +37,12 @@ class BreedGym(spaces.Env):
             raise NotImplementedError("rendering is not part of the accelerated hot path")
         self.simulator = Simulator(**kwargs)
         if isinstance(initial_population, (str, Path)):
+            if Path(initial_population) == GENOME_FILE and not GENOME_FILE.exists():
+                raise FileNotFoundError(
+                    f"{GENOME_FILE}: the reference's default population (a 370 x 10k blob its repository strips, "
+                    ".MISSING_LARGE_BLOBS) is not shipped here either -- pass initial_population= (a .npy path or an "
+                    "(n, M, 2) array; breedgym_amd.synthetic.synthetic_genotypes makes one of the same statistics)"
+                )
             germplasm = self.simulator.load_population(initial_population)
         else:
             germplasm = self.simulator.device_put(initial_population)

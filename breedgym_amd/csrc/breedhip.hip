@@ -66,6 +66,7 @@ struct bh_ctx {
   uint8_t *d_Z[2] = {nullptr, nullptr};
   int64_t z_cap[2] = {0, 0};  // bytes
   bool prefetch = true;
+  int layout = bh::LAYOUT_ORIGINAL;  // bh_set_threefry_layout
   struct {
     bool valid = false;
     int buf = 0;
@@ -168,6 +169,7 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
   m.key1 = key1;
   m.nkeys = (uint32_t)(dh ? B + 1 : 2 * B + 1);
   m.dh = dh;
+  m.layout = c->layout;
   return m;
 }
 
@@ -883,7 +885,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
   }
 
   // Simulator.cross: keys = split(key, 2B+1); key <- keys[0]
-  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)nkeys, 0u);
+  const bh::u32x2 nk = bh::split_at(sim_key[0], sim_key[1], (uint32_t)nkeys, 0u, c->layout);
 
   if (rows > 0) {
     const int buf = c->last_buf;
@@ -1267,7 +1269,7 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
     return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 1 <= n_crosses <= min(k(k-1)/2, n)");
   if (n > 8192 || n_pairs > 8192 || n_envs > 65535)
     return fail(BH_ERR_UNSUPPORTED, "bh_selection_actions: n and k(k-1)/2 must be <= 8192");
-  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u);
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u, c->layout);
   if (n_envs > 0) {
     if (!d_scores || !d_actions) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: null device pointer");
     bh::SelectionParams p{};
@@ -1286,6 +1288,7 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
     p.P_pairs = 2;
     while (p.P_pairs < n_pairs) p.P_pairs <<= 1;
     p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_pairs)) / std::log(4294967295.0));
+    p.layout = c->layout;
     const int PK = std::max(p.P_top, p.P_pairs);
     const size_t lds = (size_t)PK * 8 + (size_t)p.P_pairs * 8 + (size_t)k * 4;
     if (lds > 64 * 1024) {
@@ -1308,12 +1311,12 @@ int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n
   if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !d_out))
     return fail(BH_ERR_BAD_ARG, "bh_founders_device: need 0 <= n <= n_germplasm");
   if (n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: too many envs");
-  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u);
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u, c->layout);
   if (n_envs * n > 0) {
     if (n_germplasm > 8192) {  // beyond one workgroup's LDS: draw on the host, copy the indices
       std::vector<int32_t> h((size_t)(n_envs * n));
       uint32_t k[2] = {env_key[0], env_key[1]};
-      if (int rc = bh_founders(k, n_envs, n_germplasm, n, h.data())) return rc;
+      if (int rc = bh_founders(k, n_envs, n_germplasm, n, c->layout, h.data())) return rc;
       BH_HIP(hipMemcpyAsync(d_out, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
       BH_HIP(hipStreamSynchronize(c->stream));
     } else {
@@ -1327,6 +1330,7 @@ int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n
       p.P = 2;
       while (p.P < n_germplasm) p.P <<= 1;
       p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_germplasm)) / std::log(4294967295.0));
+      p.layout = c->layout;
       const size_t lds = (size_t)p.P * 16;
       if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::founders_kernel),
@@ -1348,18 +1352,30 @@ void bh_key_from_seed(uint64_t seed, uint32_t key[2]) {
   key[1] = (uint32_t)(seed & 0xFFFFFFFFull);
 }
 
-int bh_key_split(const uint32_t key[2], int64_t num, uint32_t *out) {
-  if (!key || !out || num < 0 || num > 0x7FFFFFFF) return fail(BH_ERR_BAD_ARG, "bh_key_split: bad arguments");
+static bool layout_ok(int layout) { return layout == bh::LAYOUT_ORIGINAL || layout == bh::LAYOUT_PARTITIONABLE; }
+
+int bh_set_threefry_layout(bh_ctx *c, int layout) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  if (!layout_ok(layout)) return fail(BH_ERR_BAD_ARG, "bh_set_threefry_layout: unknown layout %d", layout);
+  if (layout != c->layout) c->pf.valid = false;  // masks made ahead belong to the other bit stream
+  c->layout = layout;
+  return BH_OK;
+}
+
+int bh_key_split(const uint32_t key[2], int64_t num, int layout, uint32_t *out) {
+  if (!key || !out || num < 0 || num > 0x7FFFFFFF || !layout_ok(layout))
+    return fail(BH_ERR_BAD_ARG, "bh_key_split: bad arguments");
   for (int64_t k = 0; k < num; ++k) {
-    const bh::u32x2 s = bh::split_at(key[0], key[1], (uint32_t)num, (uint32_t)k);
+    const bh::u32x2 s = bh::split_at(key[0], key[1], (uint32_t)num, (uint32_t)k, layout);
     out[2 * k] = s.x;
     out[2 * k + 1] = s.y;
   }
   return BH_OK;
 }
 
-int bh_permutation(const uint32_t key_in[2], int64_t n, int32_t *out) {
-  if (!key_in || n < 0 || (n > 0 && !out) || n > 0x7FFFFFFF) return fail(BH_ERR_BAD_ARG, "bh_permutation: bad arguments");
+int bh_permutation(const uint32_t key_in[2], int64_t n, int layout, int32_t *out) {
+  if (!key_in || n < 0 || (n > 0 && !out) || n > 0x7FFFFFFF || !layout_ok(layout))
+    return fail(BH_ERR_BAD_ARG, "bh_permutation: bad arguments");
   // jax `_shuffle`: ceil(3 ln n / ln(2^32 - 1)) rounds of a stable sort by fresh random words.
   // Sorting (random word << 32 | current position) with an ordinary sort IS that stable sort.
   uint32_t key[2] = {key_in[0], key_in[1]};
@@ -1372,14 +1388,19 @@ int bh_permutation(const uint32_t key_in[2], int64_t n, int32_t *out) {
   std::iota(x.begin(), x.end(), 0);
   const int64_t L = n + (n & 1), h = L / 2;
   for (int rd = 0; rd < rounds; ++rd) {
-    const bh::u32x2 nk = bh::split_at(key[0], key[1], 2u, 0u), sub = bh::split_at(key[0], key[1], 2u, 1u);
+    const bh::u32x2 nk = bh::split_at(key[0], key[1], 2u, 0u, layout), sub = bh::split_at(key[0], key[1], 2u, 1u, layout);
     key[0] = nk.x;
     key[1] = nk.y;
-    for (int64_t i = 0; i < h; ++i) {  // random_bits(sub, n): odd n is padded with a 0 counter
-      const uint32_t c1 = (i + h < n) ? (uint32_t)(i + h) : 0u;
-      const bh::u32x2 o = bh::threefry2x32(sub.x, sub.y, (uint32_t)i, c1);
-      kv[(size_t)i] = ((uint64_t)o.x << 32) | (uint64_t)i;
-      if (i + h < n) kv[(size_t)(i + h)] = ((uint64_t)o.y << 32) | (uint64_t)(i + h);
+    if (layout == bh::LAYOUT_PARTITIONABLE) {
+      for (int64_t i = 0; i < n; ++i)
+        kv[(size_t)i] = ((uint64_t)bh::bits_word_partitionable(sub.x, sub.y, (uint32_t)i) << 32) | (uint64_t)i;
+    } else {
+      for (int64_t i = 0; i < h; ++i) {  // random_bits(sub, n): odd n is padded with a 0 counter
+        const uint32_t c1 = (i + h < n) ? (uint32_t)(i + h) : 0u;
+        const bh::u32x2 o = bh::threefry2x32(sub.x, sub.y, (uint32_t)i, c1);
+        kv[(size_t)i] = ((uint64_t)o.x << 32) | (uint64_t)i;
+        if (i + h < n) kv[(size_t)(i + h)] = ((uint64_t)o.y << 32) | (uint64_t)(i + h);
+      }
     }
     std::sort(kv.begin(), kv.end());
     for (int64_t i = 0; i < n; ++i) y[(size_t)i] = x[(size_t)(uint32_t)kv[(size_t)i]];
@@ -1389,14 +1410,14 @@ int bh_permutation(const uint32_t key_in[2], int64_t n, int32_t *out) {
   return BH_OK;
 }
 
-int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n, int32_t *out) {
+int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n, int layout, int32_t *out) {
   if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !out))
     return fail(BH_ERR_BAD_ARG, "bh_founders: need 0 <= n <= n_germplasm");
   std::vector<uint32_t> keys((size_t)(2 * (n_envs + 1)));
-  if (int rc = bh_key_split(env_key, n_envs + 1, keys.data())) return rc;
+  if (int rc = bh_key_split(env_key, n_envs + 1, layout, keys.data())) return rc;
   std::vector<int32_t> perm((size_t)n_germplasm);
   for (int64_t e = 0; e < n_envs; ++e) {
-    if (int rc = bh_permutation(&keys[(size_t)(2 * (e + 1))], n_germplasm, perm.data())) return rc;
+    if (int rc = bh_permutation(&keys[(size_t)(2 * (e + 1))], n_germplasm, layout, perm.data())) return rc;
     std::copy(perm.begin(), perm.begin() + n, out + e * n);
   }
   env_key[0] = keys[0];

@@ -50,6 +50,7 @@ struct MaskParams {
   uint32_t key0, key1;  // the call's simulator key
   uint32_t nkeys;       // keys split off it: 2*B + 1, or B + 1 for double haploids
   int32_t dh;           // 1: both gametes of cross c use keys[1 + c] (one gamete, doubled)
+  int32_t layout;       // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE (threefry.h)
 };
 
 __device__ __forceinline__ int xcd_row(int b, int n);
@@ -265,9 +266,16 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   {
     const uint32_t q = (lane >> 1) & 1u, w = lane & 1u;
     const uint32_t kidx = p.dh ? 1u + (uint32_t)c : 1u + 2u * (uint32_t)c + q;
-    const uint32_t gw = iota_word_even(p.key0, p.key1, 2u * p.nkeys, 2u * kidx + w);
-    const uint32_t g0 = __shfl(gw, lane & ~1), g1 = __shfl(gw, lane | 1);
-    const uint32_t rw = threefry2x32(g0, g1, w, w + 2u).x;
+    uint32_t rw;
+    if (p.layout == LAYOUT_PARTITIONABLE) {  // key k = TF(key, (0, k)); lanes 2q, 2q+1 both make gamete q's
+      const u32x2 gk = threefry2x32(p.key0, p.key1, 0u, kidx);
+      const u32x2 rk = threefry2x32(gk.x, gk.y, 0u, 0u);  // split(gamete_key, 2)[0]
+      rw = w ? rk.y : rk.x;
+    } else {
+      const uint32_t gw = iota_word_even(p.key0, p.key1, 2u * p.nkeys, 2u * kidx + w);
+      const uint32_t g0 = __shfl(gw, lane & ~1), g1 = __shfl(gw, lane | 1);
+      rw = threefry2x32(g0, g1, w, w + 2u).x;
+    }
     rk00 = __builtin_amdgcn_readlane(rw, 0);
     rk01 = __builtin_amdgcn_readlane(rw, 1);
     rk10 = __builtin_amdgcn_readlane(rw, 2);
@@ -319,11 +327,72 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     }                                                                                                               \
   }
 
+  /* The partitionable layout draws every marker from its own call, counter (0, m), word o0 ^ o1: the same    \
+     two-chain block once for the markers [0, half) of both gametes and once for [half, M) (their counters    \
+     are the second-counter table of the original layout; its 0 for the slot past an odd M meets a zero        \
+     threshold).  Twice the integer work per marker. */                                                         \
+#define BH_TRIP_P(T_, J_, TA_, TB_, C1_)                                                                            \
+  {                                                                                                                 \
+    uint32_t a0 = rk00, a1 = (J_) + rk01, b0 = rk10, b1 = (J_) + rk11;                                              \
+    asm volatile(BH_TFA BH_TFB                                                                                      \
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                           \
+                 : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
+                   "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),              \
+                   "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                         \
+    uint32_t c0 = rk00, c1 = (C1_) + rk01, d0 = rk10, d1 = (C1_) + rk11;                                            \
+    asm volatile(BH_TFA BH_TFB                                                                                      \
+                 : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)                                                           \
+                 : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
+                   "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),              \
+                   "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                         \
+    uint64_t sA0 = __ballot((a0 ^ a1) < (TA_)), sB0 = __ballot((c0 ^ c1) < (TB_));                                  \
+    uint64_t sA1 = __ballot((b0 ^ b1) < (TA_)), sB1 = __ballot((d0 ^ d1) < (TB_));                                  \
+    if (p.alwA) {                                                                                                   \
+      const uint64_t xa = p.alwA[(T_)], xb = p.alwB[(T_)];                                                          \
+      sA0 |= xa;                                                                                                    \
+      sA1 |= xa;                                                                                                    \
+      sB0 |= xb;                                                                                                    \
+      sB1 |= xb;                                                                                                    \
+    }                                                                                                               \
+    if (lane == 0) {                                                                                                \
+      ulonglong2 *dstw = reinterpret_cast<ulonglong2 *>(S + 4 * (T_));                                              \
+      dstw[0] = make_ulonglong2(sA0, sB0);                                                                          \
+      dstw[1] = make_ulonglong2(sA1, sB1);                                                                          \
+    }                                                                                                               \
+  }
+
 #if defined(BH_ABLATE_MASK_NOLOAD)  // timing experiments only: the mask role without its table loads (wrong masks)
 #define BH_TLOAD(r_, v_, s_) ((v_) + (s_))
 #else
 #define BH_TLOAD(r_, v_, s_) __builtin_amdgcn_raw_buffer_load_b32(r_, v_, s_, 0)
 #endif
+  if (p.layout == LAYOUT_PARTITIONABLE)
+  {
+    int t = wv;
+    uint32_t j = (uint32_t)wv * 64u + lane;
+    uint32_t soff = (uint32_t)wv * 256u;
+    constexpr uint32_t STEP = 256u * WAVES;
+    uint32_t tA0 = BH_TLOAD(rA, voff, soff);
+    uint32_t tB0 = BH_TLOAD(rB, voff, soff);
+    uint32_t cB0 = BH_TLOAD(rC, voff, soff);
+    uint32_t tA1 = BH_TLOAD(rA, voff, soff + STEP);
+    uint32_t tB1 = BH_TLOAD(rB, voff, soff + STEP);
+    uint32_t cB1 = BH_TLOAD(rC, voff, soff + STEP);
+    while (t < p.nwh) {
+      BH_TRIP_P(t, j, tA0, tB0, cB0)
+      tA0 = BH_TLOAD(rA, voff, soff + 2u * STEP);
+      tB0 = BH_TLOAD(rB, voff, soff + 2u * STEP);
+      cB0 = BH_TLOAD(rC, voff, soff + 2u * STEP);
+      if (t + WAVES < p.nwh) BH_TRIP_P(t + WAVES, j + 64u * WAVES, tA1, tB1, cB1)
+      tA1 = BH_TLOAD(rA, voff, soff + 3u * STEP);
+      tB1 = BH_TLOAD(rB, voff, soff + 3u * STEP);
+      cB1 = BH_TLOAD(rC, voff, soff + 3u * STEP);
+      t += 2 * WAVES;
+      j += 128u * WAVES;
+      soff += 2u * STEP;
+    }
+  }
+  else
   {
     int t = wv;
     uint32_t j = (uint32_t)wv * 64u + lane;
@@ -350,6 +419,7 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     }
   }
 #undef BH_TRIP
+#undef BH_TRIP_P
 #undef BH_TLOAD
   if (tid == 0) {
     S[4 * p.nwh + 1] = 0;  // the word behind the last B words (funnel shifts read one ahead)
@@ -911,23 +981,29 @@ struct FoundersParams {
   int32_t *out;  // (E, n)
   uint32_t key0, key1;
   int32_t E, N, n, P, rounds;
+  int32_t layout;  // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE
 };
 
 __global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
   extern __shared__ __align__(16) uint64_t fk[];  // P keys, then 2 x P int32 orders
   int32_t *x = reinterpret_cast<int32_t *>(fk + p.P), *y = x + p.P;
   const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e));
+  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e), p.layout);
   for (int i = tid; i < p.N; i += nt) x[i] = i;
   const int L = p.N + (p.N & 1), h = L >> 1;
   for (int rd = 0; rd < p.rounds; ++rd) {
-    const u32x2 nk = split_at(k.x, k.y, 2u, 0u), sub = split_at(k.x, k.y, 2u, 1u);
+    const u32x2 nk = split_at(k.x, k.y, 2u, 0u, p.layout), sub = split_at(k.x, k.y, 2u, 1u, p.layout);
     k = nk;
-    for (int i = tid; i < h; i += nt) {  // random_bits(sub, N): odd N is padded with a 0 counter
-      const bool second = i + h < p.N;
-      const u32x2 o = threefry2x32(sub.x, sub.y, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
-      fk[i] = ((uint64_t)o.x << 32) | (uint32_t)i;
-      if (second) fk[i + h] = ((uint64_t)o.y << 32) | (uint32_t)(i + h);
+    if (p.layout == LAYOUT_PARTITIONABLE) {
+      for (int i = tid; i < p.N; i += nt)
+        fk[i] = ((uint64_t)bits_word_partitionable(sub.x, sub.y, (uint32_t)i) << 32) | (uint32_t)i;
+    } else {
+      for (int i = tid; i < h; i += nt) {  // random_bits(sub, N): odd N is padded with a 0 counter
+        const bool second = i + h < p.N;
+        const u32x2 o = threefry2x32(sub.x, sub.y, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
+        fk[i] = ((uint64_t)o.x << 32) | (uint32_t)i;
+        if (second) fk[i + h] = ((uint64_t)o.y << 32) | (uint32_t)(i + h);
+      }
     }
     for (int i = p.N + tid; i < p.P; i += nt) fk[i] = ~0ull;
     __syncthreads();

@@ -38,18 +38,23 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, int P) {
 // jax.random.permutation(key, N) into x (LDS, N int32; y is scratch of the same size; keys holds
 // P >= N 64-bit words).  Returns the buffer that holds the result (x or y).
 __device__ __forceinline__ int32_t *shuffle_lds(u32x2 k, int N, int P, int rounds, uint64_t *keys, int32_t *x,
-                                                int32_t *y) {
+                                                int32_t *y, int layout) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < N; i += nt) x[i] = i;
   const int L = N + (N & 1), h = L >> 1;
   for (int rd = 0; rd < rounds; ++rd) {
-    const u32x2 nk = split_at(k.x, k.y, 2u, 0u), sub = split_at(k.x, k.y, 2u, 1u);
+    const u32x2 nk = split_at(k.x, k.y, 2u, 0u, layout), sub = split_at(k.x, k.y, 2u, 1u, layout);
     k = nk;
-    for (int i = tid; i < h; i += nt) {  // random_bits(sub, N): odd N is padded with a 0 counter
-      const bool second = i + h < N;
-      const u32x2 o = threefry2x32(sub.x, sub.y, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
-      keys[i] = ((uint64_t)o.x << 32) | (uint32_t)i;
-      if (second) keys[i + h] = ((uint64_t)o.y << 32) | (uint32_t)(i + h);
+    if (layout == LAYOUT_PARTITIONABLE) {
+      for (int i = tid; i < N; i += nt)
+        keys[i] = ((uint64_t)bits_word_partitionable(sub.x, sub.y, (uint32_t)i) << 32) | (uint32_t)i;
+    } else {
+      for (int i = tid; i < h; i += nt) {  // random_bits(sub, N): odd N is padded with a 0 counter
+        const bool second = i + h < N;
+        const u32x2 o = threefry2x32(sub.x, sub.y, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
+        keys[i] = ((uint64_t)o.x << 32) | (uint32_t)i;
+        if (second) keys[i + h] = ((uint64_t)o.y << 32) | (uint32_t)(i + h);
+      }
     }
     for (int i = N + tid; i < P; i += nt) keys[i] = ~0ull;
     __syncthreads();
@@ -155,6 +160,7 @@ struct SelectionParams {
   int32_t n_pairs;   // k (k - 1) / 2
   int32_t P_pairs;   // power of two >= n_pairs
   int32_t rounds;    // shuffle rounds for n_pairs elements
+  int32_t layout;    // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE
 };
 
 __global__ __launch_bounds__(1024) void selection_actions_kernel(const SelectionParams p) {
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(1024) void selection_actions_kernel(const Selection
   __syncthreads();
 
   // random subset of the diallel pairs, without replacement
-  const u32x2 ke = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e));
-  const int32_t *perm = shuffle_lds(ke, p.n_pairs, p.P_pairs, p.rounds, sk, x, y);
+  const u32x2 ke = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e), p.layout);
+  const int32_t *perm = shuffle_lds(ke, p.n_pairs, p.P_pairs, p.rounds, sk, x, y, p.layout);
 
   // slot s takes pair perm[s / n_offspring]; pair rank t -> (i, j), i < j, row-major upper triangle
   for (int s = tid; s < p.n; s += nt) {

@@ -8,6 +8,13 @@
 //       i >= h : TF(key, (i-h, i)).o1
 //   split(key, num)      = threefry_iota(key, 2*num) reshaped (num, 2)
 //   random_bits(key, n)  = threefry_iota(key, n)
+// Those are JAX's ORIGINAL layouts (jax_threefry_partitionable = False: the default up to jax 0.4.x, under
+// which the reference's seeded expectations were recorded).  Since jax 0.5 the default is the
+// PARTITIONABLE form (jax/_src/prng.py, _threefry_split_foldlike / _threefry_random_bits_partitionable):
+// counters are the 64-bit positions (hi, lo) = (0, i), one Threefry call per element,
+//   split(key, num)[k]      = TF(key, (0, k))            both output words are the new key
+//   random_bits(key, n)[i]  = o0 ^ o1 of TF(key, (0, i))  (32-bit draws)
+// Both are selectable (bh_set_threefry_layout); everything built on split / random_bits follows.
 #pragma once
 #include <stdint.h>
 
@@ -66,9 +73,19 @@ BH_HD uint32_t iota_word_even(uint32_t k0, uint32_t k1, uint32_t n, uint32_t j) 
   return first ? o.x : o.y;
 }
 
+enum { LAYOUT_ORIGINAL = 0, LAYOUT_PARTITIONABLE = 1 };
+
 // split(key, num)[k] without materialising the other keys
-BH_HD u32x2 split_at(uint32_t k0, uint32_t k1, uint32_t num, uint32_t k) {
+BH_HD u32x2 split_at(uint32_t k0, uint32_t k1, uint32_t num, uint32_t k, int layout = LAYOUT_ORIGINAL) {
+  if (layout == LAYOUT_PARTITIONABLE) return threefry2x32(k0, k1, 0u, k);
   return {iota_word_even(k0, k1, 2u * num, 2u * k), iota_word_even(k0, k1, 2u * num, 2u * k + 1u)};
+}
+
+// random_bits(key, n)[i] in the partitionable layout (the original one hashes positions in pairs: see the
+// loops that use it)
+BH_HD uint32_t bits_word_partitionable(uint32_t k0, uint32_t k1, uint32_t i) {
+  const u32x2 o = threefry2x32(k0, k1, 0u, i);
+  return o.x ^ o.y;
 }
 
 // integer threshold t with  uniform_f32(bits) < r  <=>  (bits >> 9) < t   (t in [0, 2^23])

@@ -10,6 +10,7 @@ bytes; bytes ``[2m, 2m+1]`` of a row are the two alleles of marker ``m`` (the re
 ``(rows, M, 2)`` bool view.
 """
 import ctypes
+import math
 from typing import Optional
 
 import numpy as np
@@ -115,6 +116,9 @@ class EngineBase:
         rows = rows_t.shape[0]
         if not lead:
             lead = (rows,)
+        if self.pitch == 2 * self.n_markers and rows_t.is_contiguous() and rows == math.prod(lead):
+            # no pad bytes: a plain reshape
+            return rows_t.view(torch.bool).view(*lead, self.n_markers, 2).as_subclass(DeviceArray)
         g = rows_t[:, : 2 * self.n_markers].view(torch.bool)
         strides, acc = [], self.pitch
         for d in reversed(lead):
@@ -163,7 +167,8 @@ class EngineBase:
 class HipEngine(EngineBase):
     """One GPU, one genetic map: thresholds and marker effects resident in HBM."""
 
-    def __init__(self, recombination_vec: np.ndarray, marker_effects: np.ndarray, device=None):
+    def __init__(self, recombination_vec: np.ndarray, marker_effects: np.ndarray, device=None,
+                 threefry_layout="original"):
         L = _lib.lib()
         if not torch.cuda.is_available() or _lib.device_count() == 0:
             raise RuntimeError(
@@ -191,6 +196,8 @@ class HipEngine(EngineBase):
         self._L = L
         self.pitch = int(L.bh_row_pitch(h))
         self.packed_pitch = int(L.bh_packed_pitch(h))
+        self.threefry_layout = "original"
+        self.set_threefry_layout(threefry_layout)
         # torch's default stream is the null stream, which is also the context's default
 
     def close(self):
@@ -338,6 +345,13 @@ class HipEngine(EngineBase):
             )
         )
         return out, key
+
+    def set_threefry_layout(self, layout) -> None:
+        """"original" (jax_threefry_partitionable off: what the reference's seeded tests were recorded under) or
+        "partitionable" (the default of jax >= 0.5): which JAX bit stream the device paths reproduce."""
+        code = _lib.layout_code(layout)
+        _lib.check(self._L.bh_set_threefry_layout(self._h, code))
+        self.threefry_layout = "partitionable" if code else "original"
 
     def set_mask_prefetch(self, enable: bool) -> None:
         """Run-ahead of the next generation's crossover masks on a side stream (default on)."""

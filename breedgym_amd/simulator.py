@@ -53,6 +53,7 @@ class Simulator:
         device=None,
         backend=None,
         *,
+        threefry_layout: str = "original",
         engine=None,
     ):
         if mutation != 0.0:
@@ -68,7 +69,14 @@ class Simulator:
         self.mutation = mutation
         # `engine=` is the seam tests use to drive the host logic without a GPU; product code
         # never passes it, so the HIP engine (and its loud failure without a device) is the default.
-        self.engine = engine if engine is not None else HipEngine(gm.recombination_vec, gm.marker_effects, device)
+        _lib.layout_code(threefry_layout)  # validates
+        self.threefry_layout = threefry_layout
+        if engine is not None:
+            self.engine = engine
+            if threefry_layout != "original":
+                engine.set_threefry_layout(threefry_layout)
+        else:
+            self.engine = HipEngine(gm.recombination_vec, gm.marker_effects, device, threefry_layout)
         self.device = self.engine.device
         self.GEBV_model = TraitModel(self, gm.marker_effects)
         if seed is None:
@@ -191,10 +199,10 @@ class Simulator:
         """n_crosses random pairs without replacement of pairs; each crossed n_offspring times."""
         rows, lead = self._rows_of(population)
         n = rows.shape[0]
-        keys = rng.split(self.random_key, 2)
+        keys = rng.split(self.random_key, 2, self.threefry_layout)
         self.random_key = keys[0]
         all_pairs = self._diallel_indices(np.arange(n))
-        pick = rng.choice_no_replace(keys[1], len(all_pairs), n_crosses)
+        pick = rng.choice_no_replace(keys[1], len(all_pairs), n_crosses, self.threefry_layout)
         pairs = np.repeat(np.asarray(all_pairs)[pick], n_offspring, axis=0).astype(np.int32)
         idx = self.engine.to_device(pairs, torch.int32).reshape(1, -1, 2)
         out = self.engine.empty_population(len(pairs))

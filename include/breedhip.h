@@ -54,6 +54,13 @@ typedef enum bh_rng_mode {
                                row b uses keys[1 + b]; pass the same index twice in d_idx */
 } bh_rng_mode;
 
+/* Counter layout of JAX's threefry PRNG (jax/_src/prng.py).  ORIGINAL: jax_threefry_partitionable = False,
+ * the default up to jax 0.4.x and the one the reference's seeded expectations were recorded under
+ * (tests/test_vec.py:132 ...): split / random_bits hash iota() cut in two halves, one call per two words.
+ * PARTITIONABLE: the default since jax 0.5: element i comes from its own call with counter (0, i); a new
+ * key is both output words, a 32-bit draw their XOR.  Same primitive, different bit streams. */
+typedef enum bh_threefry_layout { BH_THREEFRY_ORIGINAL = 0, BH_THREEFRY_PARTITIONABLE = 1 } bh_threefry_layout;
+
 typedef struct bh_ctx bh_ctx; /* opaque */
 
 const char *bh_version(void);
@@ -188,13 +195,16 @@ int bh_optimal_haploid(bh_ctx *ctx, const uint8_t *d_pop, int64_t n_rows, const 
 /* ---- host-side RNG plumbing (JAX threefry key chains) -------------------------------- */
 /* jax.random.key(seed) (vec_env.py:115, Simulator.set_seed). */
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]);
-/* jax.random.split(key, num) -> out (num, 2). */
-int bh_key_split(const uint32_t key[2], int64_t num, uint32_t *out);
+/* Which threefry layout the device paths of a context follow (bh_cross*, bh_founders_device,
+ * bh_selection_actions); default BH_THREEFRY_ORIGINAL.  Masks made ahead are dropped on a change. */
+int bh_set_threefry_layout(bh_ctx *ctx, int layout);
+/* jax.random.split(key, num) -> out (num, 2); `layout`: bh_threefry_layout. */
+int bh_key_split(const uint32_t key[2], int64_t num, int layout, uint32_t *out);
 /* jax.random.permutation(key, n) -> out (n) int32. */
-int bh_permutation(const uint32_t key[2], int64_t n, int32_t *out);
+int bh_permutation(const uint32_t key[2], int64_t n, int layout, int32_t *out);
 /* The founder draw of VecBreedGym.reset (vec_env.py:120-128): keys = split(env_key, E+1);
  * env_key <- keys[0]; env e takes permutation(keys[1+e], N)[:n].  out (E, n) int32 host. */
-int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n, int layout,
                 int32_t *out);
 
 /* The same draw made on the device (one workgroup per env: Threefry + bitonic sort in LDS),

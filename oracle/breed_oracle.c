@@ -44,6 +44,14 @@ void bo_key_from_seed(uint64_t seed, uint32_t key[2]) {
   key[1] = (uint32_t)(seed & 0xFFFFFFFFu);
 }
 
+/* Which of JAX's two counter layouts split / random_bits follow (jax/_src/prng.py): 0 = the original one
+ * (jax_threefry_partitionable = False, default up to jax 0.4.x: _threefry_split_original /
+ * _threefry_random_bits_original), 1 = the partitionable one (default since jax 0.5:
+ * _threefry_split_foldlike / _threefry_random_bits_partitionable).  Test-infrastructure global. */
+static int g_layout = 0;
+void bo_set_threefry_layout(int layout) { g_layout = layout ? 1 : 0; }
+int bo_threefry_layout(void) { return g_layout; }
+
 /* jax `threefry_2x32(key, count)` for count = iota(n): the counter vector is
  * padded to even length with a 0, cut in two halves (x0 = first, x1 = second),
  * hashed pairwise, and the two output halves are concatenated again. */
@@ -60,10 +68,23 @@ static void threefry_iota(const uint32_t key[2], int64_t n, uint32_t *out) {
 }
 
 void bo_random_bits(const uint32_t key[2], int64_t n, uint32_t *out) {
+  if (g_layout) { /* element i: counter (hi, lo) = (0, i) of a 64-bit iota, 32-bit draw = o0 ^ o1 */
+    for (int64_t i = 0; i < n; ++i) {
+      uint32_t o0, o1;
+      bo_threefry2x32(key[0], key[1], 0u, (uint32_t)i, &o0, &o1);
+      out[i] = o0 ^ o1;
+    }
+    return;
+  }
   threefry_iota(key, n, out);
 }
 
 void bo_split(const uint32_t key[2], int64_t num, uint32_t *out) {
+  if (g_layout) { /* fold-like: key k = both output words of TF(key, (0, k)) */
+    for (int64_t k = 0; k < num; ++k)
+      bo_threefry2x32(key[0], key[1], 0u, (uint32_t)k, &out[2 * k], &out[2 * k + 1]);
+    return;
+  }
   /* counts = iota(2*num); result reshaped (num, 2) */
   threefry_iota(key, 2 * num, out);
 }

@@ -48,6 +48,8 @@ void bo_key_from_seed(uint64_t seed, uint32_t key[2]);
 void bo_split(const uint32_t key[2], int64_t num, uint32_t *out);
 
 /* jax random_bits(key, 32, (n,)) -> out[n] (odd n padded with a 0 counter). */
+void bo_set_threefry_layout(int layout); /* 0 original, 1 partitionable (jax >= 0.5 default) */
+int bo_threefry_layout(void);
 void bo_random_bits(const uint32_t key[2], int64_t n, uint32_t *out);
 
 /* jax.random.uniform float32 in [0,1) from one 32-bit word. */

@@ -56,6 +56,18 @@ def _key(key):
     return k
 
 
+LAYOUTS = {"original": 0, "partitionable": 1}
+
+
+def set_threefry_layout(layout) -> None:
+    """Which JAX counter layout split / random_bits (and everything on top) follow; a process-wide switch."""
+    lib().bo_set_threefry_layout(ctypes.c_int(LAYOUTS[layout] if isinstance(layout, str) else int(layout)))
+
+
+def threefry_layout() -> str:
+    return "partitionable" if lib().bo_threefry_layout() else "original"
+
+
 def threefry2x32(k0, k1, c0, c1):
     o0, o1 = ctypes.c_uint32(), ctypes.c_uint32()
     lib().bo_threefry2x32(

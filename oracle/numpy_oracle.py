@@ -54,11 +54,26 @@ def _threefry_iota(key, n):
     return np.concatenate([o0, o1])[:n]
 
 
+LAYOUT = "original"  # or "partitionable" (the default of jax >= 0.5); set_threefry_layout() switches
+
+
+def set_threefry_layout(layout):
+    global LAYOUT
+    assert layout in ("original", "partitionable")
+    LAYOUT = layout
+
+
 def random_bits(key, n):
+    if LAYOUT == "partitionable":  # jax/_src/prng.py _threefry_random_bits_partitionable: counts (0, i), hi ^ lo
+        o0, o1 = threefry2x32(key, np.zeros(n, _U32), np.arange(n, dtype=_U32))
+        return o0 ^ o1
     return _threefry_iota(key, n)
 
 
 def split(key, num):
+    if LAYOUT == "partitionable":  # _threefry_split_foldlike: key k = both words of TF(key, (0, k))
+        o0, o1 = threefry2x32(key, np.zeros(num, _U32), np.arange(num, dtype=_U32))
+        return np.stack([o0, o1], axis=1)
     return _threefry_iota(key, 2 * num).reshape(num, 2)
 
 

@@ -21,6 +21,10 @@ class OracleEngine(EngineBase):
         self.pitch = (2 * self.n_markers + 15) // 16 * 16
         self.packed_pitch = 16 * ((self.n_markers + 63) // 64)
         self.calls = {"cross": 0, "gather": 0, "gebv": 0, "reward_max": 0, "topk": 0}
+        self.threefry_layout = "original"
+
+    def set_threefry_layout(self, layout):
+        self.threefry_layout = layout
 
     def _g(self, rows_t):  # (rows, pitch) -> (rows, M, 2) numpy u8
         return rows_t.numpy()[:, : 2 * self.n_markers].reshape(-1, self.n_markers, 2)
@@ -37,6 +41,7 @@ class OracleEngine(EngineBase):
 
     def cross(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, out, gebv=None, reward=None, reward_next=None):
         self.calls["cross"] += 1
+        co.set_threefry_layout(self.threefry_layout)
         if reward_next is not None:
             reward_next[:n_envs] = float("-inf")
         p = self._g(pool)[: n_envs * pool_rows].reshape(n_envs, pool_rows, self.n_markers, 2)
@@ -135,11 +140,13 @@ class OracleEngine(EngineBase):
         return torch.from_numpy(out.reshape(*s.shape[:-1], k))
 
     def founders(self, env_key, n_envs, n_germplasm, n):
+        co.set_threefry_layout(self.threefry_layout)
         f, k = co.founders(env_key, n_envs, n_germplasm, n)
         return torch.from_numpy(f.reshape(-1)), k
 
     def selection_actions(self, scores, k, n_crosses, env_key):
         s = scores.as_subclass(torch.Tensor).to(torch.float32).numpy() if isinstance(scores, torch.Tensor) else np.asarray(scores, np.float32)
+        co.set_threefry_layout(self.threefry_layout)
         a, key = co.selection_actions(s, k, n_crosses, env_key)
         return torch.from_numpy(a), key
 

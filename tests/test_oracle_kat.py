@@ -23,22 +23,91 @@ def test_threefry_random123_kat(impl):
         assert list(got) == v["out"]
 
 
-@pytest.mark.parametrize("mod", [co, no])
-def test_jax_documented_values(mod):
-    """`random.split(PRNGKey(0))`, `random.uniform(PRNGKey(0))` as printed in JAX's docs
-    (original, non-partitionable threefry layouts)."""
-    d = KAT["jax_docs_original_layout"]
-    k0 = mod.key_from_seed(0)
-    assert mod.split(k0, 2).tolist() == d["split_PRNGKey0_num2"]
-    bits = mod.random_bits(k0, 1)
-    u = co.uniform_f32(bits)[0]
-    assert abs(float(u) - d["uniform_PRNGKey0"]) < 5e-9
-    # normal = sqrt(2) * erfinv(uniform in (-1, 1)): same word, affine map
+def _set_layout(layout):
+    co.set_threefry_layout(layout)
+    no.set_threefry_layout(layout)
+
+
+@pytest.fixture(autouse=True)
+def _original_layout_afterwards():
+    yield
+    _set_layout("original")
+
+
+def _normal_scalar(mod, key):
+    """jax.random.normal(key): sqrt(2) * erfinv(uniform in (-1, 1)) of the first 32-bit draw."""
     from scipy.special import erfinv
 
+    u = co.uniform_f32(mod.random_bits(key, 1))[0]
     lo = np.nextafter(np.float32(-1), np.float32(0))
     x = np.float32(u) * (np.float32(1) - lo) + lo
-    assert abs(float(np.sqrt(2) * erfinv(np.float64(x))) - d["normal_PRNGKey0"]) < 1e-6
+    return float(np.sqrt(2) * erfinv(np.float64(x)))
+
+
+@pytest.mark.parametrize("mod", [co, no])
+def test_jax_documented_values(mod):
+    """`random.split`, `random.uniform`, `random.normal` as printed in JAX's docs under the original
+    (non-partitionable) threefry layouts: PRNGKey(0), and key(42) with its subkey from the random-numbers tutorial."""
+    d = KAT["jax_docs_original_layout"]
+    _set_layout("original")
+    k0 = mod.key_from_seed(0)
+    assert mod.split(k0, 2).tolist() == d["split_PRNGKey0_num2"]
+    u = co.uniform_f32(mod.random_bits(k0, 1))[0]
+    assert abs(float(u) - d["uniform_PRNGKey0"]) < 5e-9
+    assert abs(_normal_scalar(mod, k0) - d["normal_PRNGKey0"]) < 1e-6
+    k42 = mod.key_from_seed(42)
+    two = mod.split(k42, 2)
+    assert two.tolist() == d["split_key42_num2"]
+    assert abs(_normal_scalar(mod, k42) - d["normal_key42"]) < 1e-6
+    assert abs(_normal_scalar(mod, two[1]) - d["normal_subkey_of_key42"]) < 1e-6
+
+
+@pytest.mark.parametrize("mod", [co, no])
+def test_jax_documented_values_partitionable(mod):
+    """The same calls as documented for jax >= 0.5, whose default is jax_threefry_partitionable = True:
+    split is fold-like (key k = TF(key, (0, k))), a 32-bit draw is o0 ^ o1 of TF(key, (0, i))."""
+    d = KAT["jax_docs_partitionable_layout"]
+    _set_layout("partitionable")
+    assert mod.split(mod.key_from_seed(0), 2).tolist() == d["split_key0_num2"]
+    assert d["split_key0_num2"][0] == KAT["threefry2x32_20"][0]["out"]  # Random123's first vector IS that key
+    assert abs(_normal_scalar(mod, mod.key_from_seed(42)) - d["normal_key42"]) < 1e-6
+
+
+def test_partitionable_layout_c_equals_numpy_and_host_library(rng, native_lib):
+    """C restatement == NumPy restatement == libbreedhip's host key plumbing under the partitionable layout:
+    split, permutation (odd and even lengths, two shuffle rounds), founders, a whole cross."""
+    from breedgym_amd import rng as hrng
+
+    _set_layout("partitionable")
+    key = co.key_from_seed(123)
+    for num in (1, 2, 3, 7, 513):
+        assert np.array_equal(co.split(key, num), no.split(key, num))
+        assert np.array_equal(hrng.split(key, num, "partitionable"), co.split(key, num))
+        assert not np.array_equal(hrng.split(key, num, "original"), co.split(key, num))
+    for n in (1, 2, 5, 64, 371, 70000):
+        assert np.array_equal(co.random_bits(key, n), no.random_bits(key, n))
+        pc = co.permutation(key, n)
+        assert np.array_equal(pc, no.permutation(key, n)) and np.array_equal(hrng.permutation(key, n, "partitionable"), pc)
+        assert sorted(pc.tolist()) == list(range(n))
+    fc, kc = co.founders(key, 3, 41, 17)
+    fn, kn = no.founders(key, 3, 41, 17)
+    fh, kh = hrng.founders(key, 3, 41, 17, "partitionable")
+    assert np.array_equal(fc, fn) and np.array_equal(fc, fh) and np.array_equal(kc, kn) and np.array_equal(kc, kh)
+    for M in (1, 2, 63, 64, 65, 1001):
+        pool = rng.integers(0, 2, (2, 5, M, 2), dtype=np.uint8)
+        idx = rng.integers(0, 5, (2, 4, 2), dtype=np.int32)
+        r = (rng.random(M) * 0.1).astype(np.float32)
+        r[0] = 0.5
+        for mode in (0, 1, 2):
+            oc, kc = co.cross(pool, idx, r, key, mode)
+            if mode < 2:
+                on, kn = no.vec_step_cross(pool, idx, r, key, mode)
+                assert np.array_equal(oc, on) and np.array_equal(kc, kn), (M, mode)
+        _set_layout("original")
+        oo, _ = co.cross(pool, idx, r, key, 0)
+        _set_layout("partitionable")
+        if M > 60:
+            assert not np.array_equal(oo, co.cross(pool, idx, r, key, 0)[0])  # a different bit stream
 
 
 def test_threshold_equivalence(rng):
