@@ -274,8 +274,11 @@ def bench_population(args, rank, world, local_rank, use_dist, barrier):
     del rows
     sp = ShardedPopulation(sim, shard, storage="bits")
     del shard
+    # every rank's rows of one global pair table, the same key on every rank: the N-rank generation is the
+    # generation one device would compute for the whole population (world-size invariant)
     prng = np.random.default_rng(3)
-    pairs = [torch.from_numpy(prng.integers(0, k, (n_local, 2), dtype=np.int32)).to(eng.device) for _ in range(2)]
+    mine = slice(rank * n_local, (rank + 1) * n_local)
+    pairs = [torch.from_numpy(prng.integers(0, k, (n_total, 2), dtype=np.int32)[mine].copy()).to(eng.device) for _ in range(2)]
     key = np.array([0, 5], np.uint32)
     for i in range(args.warmup):
         sp.select_and_cross(k, pairs[i % 2], key)
@@ -301,8 +304,8 @@ def bench_population(args, rank, world, local_rank, use_dist, barrier):
                 "workload": f"BASELINE configs[3]: {n_total} individuals x 100k markers over {world} GPU(s), 8192 per rank, "
                             f"top-{k} by GEBV, every rank crosses its shard from the replicated winners",
                 "n_markers": M, "crosses_per_step_per_gpu": n_local, "storage": "bits",
-                "collectives": f"all-gather of {k} (score, index) candidates per rank; all-gather of the winners' "
-                               f"bit-plane rows ({k * pp / 1e6:.0f} MB in total per generation)",
+                "collectives": f"all-gather of {min(k, n_local)} (score, index) candidates per rank; one all-reduce of the "
+                               f"winners' bit-plane rows ({k * pp / 1e6:.0f} MB buffer, each row filled by its owner)",
             },
         }
         print(json.dumps(line), flush=True)
@@ -375,6 +378,9 @@ def main():
     # storage="bits" (default): the populations live as bit planes between steps; every step still
     # writes and returns the byte-layout observation (observations="eager").
     env = make_env("shared")
+    # N ranks = one vector env of N x 16 envs, 16 per rank: the same seed everywhere, every rank draws its envs'
+    # founders through its env window (world-size invariant; still no collective on the data path)
+    env.simulator.engine.set_env_window(rank * N_ENVS, world * N_ENVS)
     dev = env.device
     arng = np.random.default_rng(2 + rank)
     actions = [
@@ -382,7 +388,7 @@ def main():
         for _ in range(16)
     ]
 
-    env.reset(seed=100 + rank)
+    env.reset(seed=100)
     dt, t_issue = time_steps(env, actions, args.steps, args.warmup, barrier)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -396,7 +402,8 @@ def main():
     ti = kern_ms_i = None
     if not args.headline_only:
         env_i = make_env("independent")
-        env_i.reset(seed=100 + rank)
+        env_i.simulator.engine.set_env_window(rank * N_ENVS, world * N_ENVS)
+        env_i.reset(seed=100)
         dt_i, _ = time_steps(env_i, actions, args.steps, args.warmup, barrier)
         ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
         if use_dist:
@@ -411,7 +418,7 @@ def main():
         for name, kw in (("byte_layout_storage", dict(storage="bytes")),
                          ("lazy_observations", dict(storage="bits", observations="lazy"))):
             env_v = make_env("shared", **kw)
-            env_v.reset(seed=100 + rank)
+            env_v.reset(seed=100)
             dt_v, _ = time_steps(env_v, actions, args.steps, args.warmup, barrier)
             kms = time_cross_launches(env_v, actions, max(20, args.steps))
             nb = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, kw["storage"], kw.get("observations", "eager"))

@@ -107,6 +107,8 @@ SIGNATURES = {
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
     "bh_set_threefry_layout": (_int, [_vp, _int]),
+    "bh_set_env_window": (_int, [_vp, _i64, _i64]),
+    "bh_set_cross_window": (_int, [_vp, _i64, _i64]),
     "bh_key_split": (_int, [_u32p, _i64, _int, _u32p]),
     "bh_permutation": (_int, [_u32p, _i64, _int, _i32p]),
     "bh_founders": (_int, [_u32p, _i64, _i64, _i64, _int, _i32p]),

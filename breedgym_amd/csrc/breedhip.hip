@@ -67,12 +67,16 @@ struct bh_ctx {
   int64_t z_cap[2] = {0, 0};  // bytes
   bool prefetch = true;
   int layout = bh::LAYOUT_ORIGINAL;  // bh_set_threefry_layout
+  // sharding windows: this context holds envs [env_offset, env_offset + n_envs) of envs_total, or crosses
+  // [cross_offset, ..) of crosses_total of one batch, and draws the keys the whole would draw (0 = no window)
+  int64_t env_offset = 0, envs_total = 0, cross_offset = 0, crosses_total = 0;
   struct {
     bool valid = false;
     int buf = 0;
     uint32_t key0 = 0, key1 = 0;
     int64_t B = 0;
     bool dh = false;
+    int64_t off = 0, total = 0;
   } pf;
   int last_buf = 1;
   // fixed-point marker effects for the int8-MFMA GEBV: one pack per group of <= 10 traits
@@ -147,7 +151,13 @@ int launch_row_mode(const bh_ctx *c, const bh::RowParams &p, int tt) {
 }
 
 // `waves` = waves per cross in the mask role (1 or 4)
-bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, int waves, bool dh) {
+// the key window of a call with B keyed crosses: (offset, total) in crosses; total == B without sharding
+struct KeyWindow {
+  int64_t off, total;
+};
+
+bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, int waves, bool dh,
+                           KeyWindow kw) {
   const int groups = 4 / waves;
   bh::MaskParams m{};
   m.Z = c->d_Z[buf];
@@ -167,7 +177,8 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
   m.group_lds = (int32_t)mask_group_lds(c);
   m.key0 = key0;
   m.key1 = key1;
-  m.nkeys = (uint32_t)(dh ? B + 1 : 2 * B + 1);
+  m.nkeys = (uint32_t)(dh ? kw.total + 1 : 2 * kw.total + 1);
+  m.key_offset = (uint32_t)kw.off;
   m.dh = dh;
   m.layout = c->layout;
   return m;
@@ -183,9 +194,9 @@ int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
 }
 
 // crossover masks of B crosses keyed off `key` into d_Z[buf], in stream order (not overlapped)
-int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bool dh) {
+int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bool dh, KeyWindow kw) {
   const int waves = waves_for(c);
-  const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves, dh);
+  const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves, dh, kw);
   const size_t lds = (size_t)m.group_lds * (4 / waves);
   if (waves == 1) {
     hipLaunchKernelGGL(bh::mask_kernel<1>, dim3((unsigned)m.n_blocks), dim3(256), lds, c->stream, m);
@@ -855,7 +866,18 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
   const bool shared = (rng_mode & BH_RNG_INDEPENDENT) == 0;
   const int64_t rows = n_envs * n_out;
   const int64_t B = shared ? n_out : rows;
-  const int64_t nkeys = dh ? B + 1 : 2 * B + 1;
+  // independent keys of a shard: the keys the whole batch would split (bh_set_cross_window, or the env window
+  // in crosses); shared keys are the same on every shard anyway
+  KeyWindow kw{0, B};
+  if (!shared) {
+    if (c->crosses_total > 0)
+      kw = {c->cross_offset, c->crosses_total};
+    else if (c->envs_total > 0)
+      kw = {c->env_offset * n_out, c->envs_total * n_out};
+    if (kw.off + B > kw.total) return fail(BH_ERR_BAD_ARG, "%s: %lld crosses at offset %lld exceed the window of %lld",
+                                           who, (long long)B, (long long)kw.off, (long long)kw.total);
+  }
+  const int64_t nkeys = dh ? kw.total + 1 : 2 * kw.total + 1;
   if (rows > 0x3FFFFFFF || n_envs * pool_rows > 0x7FFFFFFF || 2 * nkeys > 0xFFFFFFFFll)
     return fail(BH_ERR_UNSUPPORTED, "%s: too many rows for 32-bit indexing", who);
   if (rows > 0) {
@@ -873,12 +895,13 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // ---- this generation's masks: made by the previous call's launch, or made now
     const int64_t zbytes = B * 16 * c->nw;
     int buf;
-    if (c->pf.valid && c->pf.key0 == sim_key[0] && c->pf.key1 == sim_key[1] && c->pf.B == B && c->pf.dh == dh) {
+    if (c->pf.valid && c->pf.key0 == sim_key[0] && c->pf.key1 == sim_key[1] && c->pf.B == B && c->pf.dh == dh &&
+        c->pf.off == kw.off && c->pf.total == kw.total) {
       buf = c->pf.buf;
     } else {  // not predicted: first call, new seed, new batch size
       buf = 1 - c->last_buf;
       if (int rc = ensure_z(c, buf, zbytes)) return rc;
-      if (int rc = launch_masks(c, buf, sim_key[0], sim_key[1], B, dh)) return rc;
+      if (int rc = launch_masks(c, buf, sim_key[0], sim_key[1], B, dh, kw)) return rc;
     }
     c->pf.valid = false;
     c->last_buf = buf;
@@ -907,7 +930,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     if (run_ahead) {
       if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
       mw = mask_waves_for_runahead(c, B);
-      mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh);
+      mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh, kw);
     }
     const bool wide = rows >= 4096;  // else one row per wave: more waves in flight
     // the per-env maximum comes out of the same launch when the GEBV does: every row wave notes its value
@@ -984,6 +1007,8 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       c->pf.key1 = nk.y;
       c->pf.B = B;
       c->pf.dh = dh;
+      c->pf.off = kw.off;
+      c->pf.total = kw.total;
     }
     if (d_gebv && !fused) {
       if (packed)
@@ -1269,7 +1294,9 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
     return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 1 <= n_crosses <= min(k(k-1)/2, n)");
   if (n > 8192 || n_pairs > 8192 || n_envs > 65535)
     return fail(BH_ERR_UNSUPPORTED, "bh_selection_actions: n and k(k-1)/2 must be <= 8192");
-  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u, c->layout);
+  const int64_t e_total = c->envs_total > 0 ? c->envs_total : n_envs, e_off = c->envs_total > 0 ? c->env_offset : 0;
+  if (e_off + n_envs > e_total) return fail(BH_ERR_BAD_ARG, "more envs than the env window holds");
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(e_total + 1), 0u, c->layout);
   if (n_envs > 0) {
     if (!d_scores || !d_actions) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: null device pointer");
     bh::SelectionParams p{};
@@ -1289,6 +1316,8 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
     while (p.P_pairs < n_pairs) p.P_pairs <<= 1;
     p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_pairs)) / std::log(4294967295.0));
     p.layout = c->layout;
+    p.E_total = (int32_t)e_total;
+    p.env_offset = (int32_t)e_off;
     const int PK = std::max(p.P_top, p.P_pairs);
     const size_t lds = (size_t)PK * 8 + (size_t)p.P_pairs * 8 + (size_t)k * 4;
     if (lds > 64 * 1024) {
@@ -1311,13 +1340,16 @@ int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n
   if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !d_out))
     return fail(BH_ERR_BAD_ARG, "bh_founders_device: need 0 <= n <= n_germplasm");
   if (n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: too many envs");
-  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(n_envs + 1), 0u, c->layout);
+  const int64_t e_total = c->envs_total > 0 ? c->envs_total : n_envs, e_off = c->envs_total > 0 ? c->env_offset : 0;
+  if (e_off + n_envs > e_total) return fail(BH_ERR_BAD_ARG, "more envs than the env window holds");
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(e_total + 1), 0u, c->layout);
   if (n_envs * n > 0) {
     if (n_germplasm > 8192) {  // beyond one workgroup's LDS: draw on the host, copy the indices
-      std::vector<int32_t> h((size_t)(n_envs * n));
+      std::vector<int32_t> h((size_t)(e_total * n));
       uint32_t k[2] = {env_key[0], env_key[1]};
-      if (int rc = bh_founders(k, n_envs, n_germplasm, n, c->layout, h.data())) return rc;
-      BH_HIP(hipMemcpyAsync(d_out, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+      if (int rc = bh_founders(k, e_total, n_germplasm, n, c->layout, h.data())) return rc;
+      BH_HIP(hipMemcpyAsync(d_out, h.data() + e_off * n, (size_t)(n_envs * n) * sizeof(int32_t), hipMemcpyHostToDevice,
+                            c->stream));
       BH_HIP(hipStreamSynchronize(c->stream));
     } else {
       bh::FoundersParams p{};
@@ -1331,6 +1363,8 @@ int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n
       while (p.P < n_germplasm) p.P <<= 1;
       p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_germplasm)) / std::log(4294967295.0));
       p.layout = c->layout;
+      p.E_total = (int32_t)e_total;
+      p.env_offset = (int32_t)e_off;
       const size_t lds = (size_t)p.P * 16;
       if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::founders_kernel),
@@ -1353,6 +1387,27 @@ void bh_key_from_seed(uint64_t seed, uint32_t key[2]) {
 }
 
 static bool layout_ok(int layout) { return layout == bh::LAYOUT_ORIGINAL || layout == bh::LAYOUT_PARTITIONABLE; }
+
+int bh_set_env_window(bh_ctx *c, int64_t env_offset, int64_t envs_total) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  if (env_offset < 0 || envs_total < 0 || (envs_total > 0 && env_offset >= envs_total) || envs_total > 0x3FFFFFFF)
+    return fail(BH_ERR_BAD_ARG, "bh_set_env_window: need 0 <= env_offset < envs_total (or 0, 0)");
+  c->env_offset = envs_total > 0 ? env_offset : 0;
+  c->envs_total = envs_total;
+  c->pf.valid = false;
+  return BH_OK;
+}
+
+int bh_set_cross_window(bh_ctx *c, int64_t cross_offset, int64_t crosses_total) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  if (cross_offset < 0 || crosses_total < 0 || (crosses_total > 0 && cross_offset >= crosses_total) ||
+      crosses_total > 0x3FFFFFFF)
+    return fail(BH_ERR_BAD_ARG, "bh_set_cross_window: need 0 <= cross_offset < crosses_total (or 0, 0)");
+  c->cross_offset = crosses_total > 0 ? cross_offset : 0;
+  c->crosses_total = crosses_total;
+  c->pf.valid = false;
+  return BH_OK;
+}
 
 int bh_set_threefry_layout(bh_ctx *c, int layout) {
   if (!c) return fail(BH_ERR_BAD_ARG, "null context");

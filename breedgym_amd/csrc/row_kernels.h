@@ -51,6 +51,8 @@ struct MaskParams {
   uint32_t nkeys;       // keys split off it: 2*B + 1, or B + 1 for double haploids
   int32_t dh;           // 1: both gametes of cross c use keys[1 + c] (one gamete, doubled)
   int32_t layout;       // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE (threefry.h)
+  uint32_t key_offset;  // cross c of this call is cross key_offset + c of the whole (sharded) batch the keys are
+                        // split for: nkeys counts that whole batch (bh_set_cross_window)
 };
 
 __device__ __forceinline__ int xcd_row(int b, int n);
@@ -265,7 +267,8 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   uint32_t rk00, rk01, rk10, rk11;
   {
     const uint32_t q = (lane >> 1) & 1u, w = lane & 1u;
-    const uint32_t kidx = p.dh ? 1u + (uint32_t)c : 1u + 2u * (uint32_t)c + q;
+    const uint32_t cg = p.key_offset + (uint32_t)c;
+    const uint32_t kidx = p.dh ? 1u + cg : 1u + 2u * cg + q;
     uint32_t rw;
     if (p.layout == LAYOUT_PARTITIONABLE) {  // key k = TF(key, (0, k)); lanes 2q, 2q+1 both make gamete q's
       const u32x2 gk = threefry2x32(p.key0, p.key1, 0u, kidx);
@@ -982,13 +985,14 @@ struct FoundersParams {
   uint32_t key0, key1;
   int32_t E, N, n, P, rounds;
   int32_t layout;  // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE
+  int32_t E_total, env_offset;  // env e here is env env_offset + e of E_total (bh_set_env_window)
 };
 
 __global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
   extern __shared__ __align__(16) uint64_t fk[];  // P keys, then 2 x P int32 orders
   int32_t *x = reinterpret_cast<int32_t *>(fk + p.P), *y = x + p.P;
   const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e), p.layout);
+  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E_total + 1), (uint32_t)(1 + p.env_offset + e), p.layout);
   for (int i = tid; i < p.N; i += nt) x[i] = i;
   const int L = p.N + (p.N & 1), h = L >> 1;
   for (int rd = 0; rd < p.rounds; ++rd) {

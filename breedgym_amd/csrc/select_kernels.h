@@ -161,6 +161,7 @@ struct SelectionParams {
   int32_t P_pairs;   // power of two >= n_pairs
   int32_t rounds;    // shuffle rounds for n_pairs elements
   int32_t layout;    // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE
+  int32_t E_total, env_offset;  // env e here is env env_offset + e of E_total (bh_set_env_window)
 };
 
 __global__ __launch_bounds__(1024) void selection_actions_kernel(const SelectionParams p) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(1024) void selection_actions_kernel(const Selection
   __syncthreads();
 
   // random subset of the diallel pairs, without replacement
-  const u32x2 ke = split_at(p.key0, p.key1, (uint32_t)(p.E + 1), (uint32_t)(1 + e), p.layout);
+  const u32x2 ke = split_at(p.key0, p.key1, (uint32_t)(p.E_total + 1), (uint32_t)(1 + p.env_offset + e), p.layout);
   const int32_t *perm = shuffle_lds(ke, p.n_pairs, p.P_pairs, p.rounds, sk, x, y, p.layout);
 
   // slot s takes pair perm[s / n_offspring]; pair rank t -> (i, j), i < j, row-major upper triangle

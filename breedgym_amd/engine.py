@@ -353,6 +353,15 @@ class HipEngine(EngineBase):
         _lib.check(self._L.bh_set_threefry_layout(self._h, code))
         self.threefry_layout = "partitionable" if code else "original"
 
+    def set_env_window(self, env_offset: int, envs_total: int) -> None:
+        """This engine's envs are envs [env_offset, ..) of envs_total: founder draws, selection shuffles and
+        independent crossover keys are those of the whole (include/breedhip.h, "sharding windows")."""
+        _lib.check(self._L.bh_set_env_window(self._h, int(env_offset), int(envs_total)))
+
+    def set_cross_window(self, cross_offset: int, crosses_total: int) -> None:
+        """One batch of crosses cut row-wise over several engines: cross b here is cross cross_offset + b."""
+        _lib.check(self._L.bh_set_cross_window(self._h, int(cross_offset), int(crosses_total)))
+
     def set_mask_prefetch(self, enable: bool) -> None:
         """Run-ahead of the next generation's crossover masks on a side stream (default on)."""
         _lib.check(self._L.bh_set_mask_prefetch(self._h, int(bool(enable))))

@@ -11,11 +11,15 @@ Two ways the hot path shards:
 * **population-sharded** -- ``ShardedPopulation``.  One large population (BASELINE config 4:
   65,536 individuals x 100k markers) split row-wise over the ranks.  Per generation:
   local GEBV -> local top-k -> all-gather of (score, global index) candidates (8 B x k per rank)
-  -> every rank computes the same global top-k -> all-gather of the selected parents' genotype
-  rows (each rank contributes the winners it owns) -> each rank crosses its own shard of the
-  next generation from the replicated parent pool.  Top-k is not an element-wise reduce-op, so
-  BASELINE's "all-reduce" is an all-gather plus an identical local selection on every rank; the
-  scalar best-GEBV reward is a real MAX all-reduce.
+  -> every rank computes the same global top-k -> the winners' genotype rows are replicated with ONE
+  all-reduce of a (k, row) buffer in which every rank has filled the rows it owns and zeroed the rest
+  (each row has exactly one owner, so the sum is the row: no counts to exchange, no host sync, no
+  padding to a largest share) -> each rank crosses its own shard of the next generation from that
+  buffer.  The scalar best-GEBV reward is a MAX all-reduce.
+
+Both are **world-size invariant**: N ranks compute, shard by shard, exactly what one device would
+compute for the whole -- the engine's sharding windows (include/breedhip.h) make every rank draw the
+keys of the whole batch and use its own part of them, and all ranks start from the same seed.
 
 Nothing here launches kernels of its own: compute goes through the engine of the wrapped env.
 """
@@ -45,14 +49,24 @@ class DistributedBreedGym:
         self.num_envs = envs_per_device * self.world_size
         self.env = VecBreedGym(num_envs=envs_per_device, initial_population=initial_population, **kwargs)
         self.device = self.env.device
+        # env e of this rank is env rank * envs_per_device + e of num_envs: founder draws, selection shuffles and
+        # independent crossover keys are those a single device would use for it
+        self.env.simulator.engine.set_env_window(self.rank * envs_per_device, self.num_envs)
 
     # the slice of a global (num_envs, ...) array this rank owns
     def local_slice(self) -> slice:
         return slice(self.rank * self.envs_per_device, (self.rank + 1) * self.envs_per_device)
 
     def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
-        # decorrelate the ranks' founder draws and crossover streams: rank r uses seed + r
-        return self.env.reset(seed=None if seed is None else seed + self.rank, options=options)
+        """The same seed on every rank: the key chains are those of one ``VecBreedGym`` of ``num_envs`` envs, each
+        rank draws from them through its env window.  (seed=None on first use: rank 0's choice is broadcast.)"""
+        if seed is None and self.env.random_key is None:
+            t = torch.randint(0, 2**31 - 1, (1,), dtype=torch.int64)
+            if self.world_size > 1:
+                t = t.to(self.device) if self.device.type == "cuda" else t
+                dist.broadcast(t, src=0, group=self.group)
+            seed = int(t.item())
+        return self.env.reset(seed=seed, options=options)
 
     def step(self, actions):
         """`actions`: this rank's (envs_per_device, n, 2) slice, or the global (num_envs, n, 2) array."""
@@ -91,9 +105,14 @@ class DistributedBreedGym:
 class ShardedPopulation:
     """One population of ``n_total`` individuals, rows ``[rank * n_local, (rank + 1) * n_local)`` here.
 
-    ``storage="bits"`` keeps the shard -- and, more to the point, the winners every rank all-gathers
-    each generation -- as bit-plane rows: 8x less HBM and 8x less on the xGMI links (at BASELINE
-    config 4: 164 MB per generation instead of 1.31 GB)."""
+    ``storage="bits"`` keeps the shard -- and, more to the point, the winners' rows every generation moves
+    between the ranks -- as bit-plane rows: 8x less HBM and 8x less on the xGMI links (at BASELINE config 4:
+    164 MB per generation instead of 1.31 GB).
+
+    World-size invariant: with the same ``key`` on every rank and ``pairs`` = the rank's rows of one global
+    (n_total, 2) pair table, the N-rank generation is the 1-rank generation of the whole population, row for
+    row (the engine's cross window makes rank r use keys ``1 + 2 (r n_local + b) + p`` of one
+    ``split(key, 2 n_total + 1)``)."""
 
     def __init__(self, simulator, local_rows: torch.Tensor, group=None, storage: str = "bytes"):
         if storage not in ("bytes", "bits"):
@@ -107,6 +126,7 @@ class ShardedPopulation:
         self._store = self.eng.pack(local_rows) if storage == "bits" else local_rows
         self.n_local = local_rows.shape[0]
         self.n_total = self.n_local * self.world_size
+        self.eng.set_cross_window(self.rank * self.n_local, self.n_total)
 
     @property
     def rows(self) -> torch.Tensor:
@@ -144,63 +164,50 @@ class ShardedPopulation:
         loc = self.eng.topk(s, kk).to(torch.int64)
         cand_s = self._all_gather(s[loc])  # (W, kk)
         cand_i = self._all_gather(loc + self.rank * self.n_local)  # (W, kk) global indices
-        # same order as jax.lax.top_k on the concatenated scores: the candidates arrive sorted per
-        # rank, ranks own ascending index ranges, so a top-k over the flat candidate list with ties
-        # to the earlier position is a top-k with ties to the lower global index
-        flat_s, flat_i = cand_s.reshape(-1), cand_i.reshape(-1)
-        order = torch.argsort(flat_i)  # candidate list in global-index order
-        best = self.eng.topk(flat_s[order], k).to(torch.int64)
-        return flat_i[order][best]
+        # jax.lax.top_k on the concatenated scores resolves ties to the lower index.  The candidate list is
+        # rank-major and, inside a rank, in the local top-k's order (ties already to the lower index), ranks own
+        # ascending index ranges: the earlier position IS the lower global index, so a top-k with ties to the
+        # earlier position needs no re-ordering of the candidates
+        best = self.eng.topk(cand_s.reshape(-1), k).to(torch.int64)
+        return cand_i.reshape(-1)[best]
 
-    def replicate_winners(self, global_idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Replicate the genotype rows of `global_idx` (k,) on every rank with one all-gather.
+    def replicate_winners(self, global_idx: torch.Tensor) -> torch.Tensor:
+        """The rows of ``global_idx`` (k,), in that order, on every rank -- (k, row bytes) in the storage layout.
 
-        Returns ``(pool, slot)``: `pool` is (W * c, pitch) -- rank r's block holds the winners it owns,
-        in the order they appear in `global_idx`, padded to c = the largest per-rank count -- and
-        `slot[j]` is the pool row of winner j.  `global_idx` is identical on every rank, so owners,
-        counts and slots are computed locally; only the rows travel."""
-        W = self.world_size
-        owner = torch.div(global_idx, self.n_local, rounding_mode="floor")
-        onehot = owner.unsqueeze(1) == torch.arange(W, device=owner.device).unsqueeze(0)  # (k, W)
-        counts = onehot.sum(dim=0)
-        pos = (onehot.cumsum(dim=0) - 1).gather(1, owner.unsqueeze(1)).squeeze(1)  # rank among the owner's winners
-        c = max(int(counts.max()), 1)
-        mine = owner == self.rank
-        local_idx = (global_idx - self.rank * self.n_local)[mine].to(torch.int32).contiguous()
-        send = torch.empty((c, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
-        if local_idx.numel():
-            self._gather_local(self._store, local_idx, send[: local_idx.numel()])
-        if local_idx.numel() < c:
-            send[local_idx.numel():].zero_()  # padding rows are never indexed; keep them valid genotypes
-        pool = self._all_gather(send).reshape(W * c, -1)
-        return pool, (owner * c + pos).to(torch.int32)
+        Every rank fills the rows it owns into a zeroed (k, row) buffer (a masked gather: rows it does not own
+        are written as zeros) and ONE all-reduce (sum over int32 words; every row has exactly one owner) makes
+        the buffer whole everywhere.  ``global_idx`` is identical on all ranks; nothing goes through the host."""
+        k = global_idx.numel()
+        local = global_idx - self.rank * self.n_local
+        mine = (local >= 0) & (local < self.n_local)
+        buf = torch.empty((k, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
+        self._gather_local(self._store, local.clamp(0, self.n_local - 1).to(torch.int32).contiguous(), buf)
+        if self.world_size == 1:
+            return buf
+        words = buf.view(torch.int32)  # row bytes are a multiple of 16
+        words.mul_(mine.to(torch.int32).unsqueeze(1))
+        dist.all_reduce(words, op=dist.ReduceOp.SUM, group=self.group)
+        return buf
 
     def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
         """The genotype rows of `global_idx` (k,), in that order, replicated on every rank (byte layout)."""
-        pool, slot = self.replicate_winners(global_idx)
-        k = global_idx.numel()
-        out = self.eng.empty_population(k)
-        if self.storage == "bits":
-            self.eng.gather_packed(pool, slot.contiguous(), k, None, out)
-        else:
-            self.eng.gather(pool, slot.contiguous(), out)
-        return out
+        pool = self.replicate_winners(global_idx)
+        return self.eng.unpack(pool) if self.storage == "bits" else pool
 
     def select_and_cross(self, k: int, pairs_local: torch.Tensor, key: np.ndarray) -> DeviceArray:
         """One generation: global top-k by GEBV (first trait), replicate the winners, cross this rank's
-        shard of the next generation.  `pairs_local` (n_local, 2) int32 indexes the k winners; the
-        crosses read the all-gathered pool in place through the winners' slots."""
+        shard of the next generation.  ``pairs_local`` (n_local, 2) int32 indexes the k winners (best first);
+        ``key`` is the simulator key, THE SAME on every rank, advanced in place as one device would."""
         scores = self.gebv()[:, 0]
         best = self.global_topk(scores, k)
-        pool, slot = self.replicate_winners(best)
+        pool = self.replicate_winners(best)
         gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
-        pairs = pairs_local.reshape(-1).to(device=slot.device, dtype=torch.int64)
-        idx = slot[pairs].reshape(1, -1, 2).contiguous()
+        idx = pairs_local.to(device=pool.device, dtype=torch.int32).reshape(1, -1, 2).contiguous()
         if self.storage == "bits":
             out = self.eng.empty_packed(self.n_local)
-            self.eng.cross_packed(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, None, gebv)
+            self.eng.cross_packed(pool, 1, k, idx, self.n_local, key, 1, out, None, gebv)
         else:
             out = self.eng.empty_population(self.n_local)
-            self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
+            self.eng.cross(pool, 1, k, idx, self.n_local, key, 1, out, gebv)
         self._store = out
         return DeviceArray.wrap(gebv)

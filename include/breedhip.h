@@ -195,6 +195,17 @@ int bh_optimal_haploid(bh_ctx *ctx, const uint8_t *d_pop, int64_t n_rows, const 
 /* ---- host-side RNG plumbing (JAX threefry key chains) -------------------------------- */
 /* jax.random.key(seed) (vec_env.py:115, Simulator.set_seed). */
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]);
+/* Sharding windows: so that N shards compute what one device would.  The keys of a call are
+ * split for the WHOLE batch and a shard uses its part of them:
+ *   env window    this context's envs are envs [env_offset, env_offset + n_envs) of envs_total:
+ *                 bh_founders_device and bh_selection_actions use split(env_key, envs_total + 1)[1 + env_offset + e]
+ *                 and advance env_key as the whole would; bh_cross* with BH_RNG_INDEPENDENT takes the window in
+ *                 crosses (x n_out).  Shared keys need no window: every shard holds the same simulator key.
+ *   cross window  one batch of crosses_total crosses cut row-wise (population-sharded): cross b of a call is
+ *                 cross cross_offset + b; takes precedence over the env window for bh_cross*.
+ * (0, 0) switches a window off (the default). */
+int bh_set_env_window(bh_ctx *ctx, int64_t env_offset, int64_t envs_total);
+int bh_set_cross_window(bh_ctx *ctx, int64_t cross_offset, int64_t crosses_total);
 /* Which threefry layout the device paths of a context follow (bh_cross*, bh_founders_device,
  * bh_selection_actions); default BH_THREEFRY_ORIGINAL.  Masks made ahead are dropped on a change. */
 int bh_set_threefry_layout(bh_ctx *ctx, int layout);

@@ -22,9 +22,34 @@ class OracleEngine(EngineBase):
         self.packed_pitch = 16 * ((self.n_markers + 63) // 64)
         self.calls = {"cross": 0, "gather": 0, "gebv": 0, "reward_max": 0, "topk": 0}
         self.threefry_layout = "original"
+        self.env_window = (0, 0)
+        self.cross_window = (0, 0)
 
     def set_threefry_layout(self, layout):
         self.threefry_layout = layout
+
+    def set_env_window(self, env_offset, envs_total):
+        self.env_window = (int(env_offset), int(envs_total))
+
+    def set_cross_window(self, cross_offset, crosses_total):
+        self.cross_window = (int(cross_offset), int(crosses_total))
+
+    def _cross_windowed(self, p, idx, key, rng_mode):
+        """The oracle has no windows: cross the WHOLE batch the window speaks of (this shard's pairs in place,
+        row 0 x row 0 elsewhere) and keep this shard's rows -- which is what the window means."""
+        n_envs, n_out = idx.shape[:2]
+        off, total = self.cross_window
+        if not total and self.env_window[1]:
+            off, total = self.env_window[0] * n_out, self.env_window[1] * n_out
+        if not (rng_mode & 1) or not total:
+            return co.cross(p, idx, self.r, key, rng_mode)
+        assert n_envs * n_out + off <= total
+        flat = np.zeros((1, total, 2), np.int32)
+        # one flat batch: env e's pool rows are offset by e * pool_rows
+        pool_rows = p.shape[1]
+        flat[0, off : off + n_envs * n_out] = (idx + (np.arange(n_envs) * pool_rows)[:, None, None]).reshape(-1, 2)
+        o, newkey = co.cross(p.reshape(1, n_envs * pool_rows, *p.shape[2:]), flat, self.r, key, rng_mode)
+        return o[0, off : off + n_envs * n_out].reshape(n_envs, n_out, *o.shape[2:]), newkey
 
     def _g(self, rows_t):  # (rows, pitch) -> (rows, M, 2) numpy u8
         return rows_t.numpy()[:, : 2 * self.n_markers].reshape(-1, self.n_markers, 2)
@@ -45,7 +70,9 @@ class OracleEngine(EngineBase):
         if reward_next is not None:
             reward_next[:n_envs] = float("-inf")
         p = self._g(pool)[: n_envs * pool_rows].reshape(n_envs, pool_rows, self.n_markers, 2)
-        o, newkey = co.cross(p, idx.numpy().reshape(n_envs, n_out, 2), self.r, key, rng_mode)
+        i = idx.numpy().reshape(n_envs, n_out, 2)
+        i = np.clip(np.where(i < 0, i + pool_rows, i), 0, pool_rows - 1).astype(np.int32)  # JAX gather rules
+        o, newkey = self._cross_windowed(p, i, key, rng_mode)
         key[:] = newkey
         out[: n_envs * n_out] = 0
         out[: n_envs * n_out, : 2 * self.n_markers] = torch.from_numpy(o.reshape(n_envs * n_out, -1))
@@ -141,12 +168,22 @@ class OracleEngine(EngineBase):
 
     def founders(self, env_key, n_envs, n_germplasm, n):
         co.set_threefry_layout(self.threefry_layout)
+        off, total = self.env_window
+        if total:  # the draw of the whole, this shard's envs kept
+            f, k = co.founders(env_key, total, n_germplasm, n)
+            return torch.from_numpy(f[off : off + n_envs].reshape(-1).copy()), k
         f, k = co.founders(env_key, n_envs, n_germplasm, n)
         return torch.from_numpy(f.reshape(-1)), k
 
     def selection_actions(self, scores, k, n_crosses, env_key):
         s = scores.as_subclass(torch.Tensor).to(torch.float32).numpy() if isinstance(scores, torch.Tensor) else np.asarray(scores, np.float32)
         co.set_threefry_layout(self.threefry_layout)
+        off, total = self.env_window
+        if total:
+            whole = np.zeros((total, s.shape[1]), np.float32)
+            whole[off : off + s.shape[0]] = s
+            a, key = co.selection_actions(whole, k, n_crosses, env_key)
+            return torch.from_numpy(a[off : off + s.shape[0]].copy()), key
         a, key = co.selection_actions(s, k, n_crosses, env_key)
         return torch.from_numpy(a), key
 

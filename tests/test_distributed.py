@@ -30,33 +30,48 @@ def _setup(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _env_sharded_worker(rank, world, port, q):
+def _env_sharded_worker(rank, world, port, q, env_rng="shared"):
     _setup(rank, world, port)
     from oracle_engine import OracleEngine
 
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector import SelectionScores
     from breedgym_amd.vector.distributed import DistributedBreedGym
     from oracle import c_oracle as co
 
     gm = synthetic_genetic_map(M, n_chr=2, seed=1)
     geno = synthetic_genotypes(N, M, seed=2)
-    env = DistributedBreedGym(3, geno, individual_per_gen=8, genetic_map=gm, reward_shaping=True,
+    E = 3 * world
+    env = DistributedBreedGym(3, geno, individual_per_gen=8, genetic_map=gm, reward_shaping=True, env_rng=env_rng,
                               engine=OracleEngine(gm.recombination_vec, gm.marker_effects))
-    assert env.num_envs == 3 * world and env.local_slice() == slice(3 * rank, 3 * rank + 3)
-    pop, _ = env.reset(seed=10)
-    global_actions = np.random.default_rng(0).integers(0, 8, (3 * world, 8, 2), dtype=np.int32)
-    new_pop, r, ter, tru, infos = env.step(global_actions)  # takes its own slice
-    # what this rank must have computed: seed 10 + rank, its slice of the actions
-    f, _ = co.founders(co.key_from_seed(10 + rank), 3, N, 8)
-    ref, _ = co.cross(geno.view(np.uint8)[f], global_actions[env.local_slice()], gm.recombination_vec,
-                      co.key_from_seed(10 + rank), 0)
-    assert np.array_equal(np.asarray(new_pop).view(np.uint8), ref)
+    assert env.num_envs == E and env.local_slice() == slice(3 * rank, 3 * rank + 3)
+    pop, _ = env.reset(seed=10)  # the same seed on every rank
+    # WORLD-SIZE INVARIANCE: what ONE VecBreedGym of 3 * world envs computes, this rank's envs of it
+    mode = 0 if env_rng == "shared" else 1
+    f, env_key = co.founders(co.key_from_seed(10), E, N, 8)
+    ref = geno.view(np.uint8)[f]
+    assert np.array_equal(np.asarray(pop).view(np.uint8), ref[env.local_slice()])
+    key = co.key_from_seed(10)
+    arng = np.random.default_rng(0)
+    for step in range(3):
+        global_actions = arng.integers(0, 8, (E, 8, 2), dtype=np.int32)
+        new_pop, r, ter, tru, infos = env.step(global_actions)  # takes its own slice
+        ref, key = co.cross(ref, global_actions, gm.recombination_vec, key, mode)
+        assert np.array_equal(np.asarray(new_pop).view(np.uint8), ref[env.local_slice()]), (rank, step)
+        assert np.array_equal(env.env.simulator.random_key, key)
     allr = env.gather_rewards(r)
-    assert allr.shape == (3 * world,) and np.allclose(allr[env.local_slice()], r)
+    assert allr.shape == (E,) and np.allclose(allr[env.local_slice()], r)
+    assert np.allclose(allr, co.gebv(ref, gm.marker_effects).max(axis=(1, 2)))
     best = env.best_reward(r)
     assert abs(best - allr.max()) < 1e-6
     g = env.all_gather(infos["GEBV"])
-    assert g.shape == (3 * world, 8, 1)
+    assert g.shape == (E, 8, 1)
+    # the selection wrapper draws its pair shuffles through the same env window
+    w = SelectionScores(env.env, k=4, n_crosses=5)
+    scores = co.gebv(ref, gm.marker_effects)[..., 0]
+    low = np.asarray(w._convert_actions(scores[env.local_slice()]))
+    ref_low, ref_env_key = co.selection_actions(scores, 4, 5, env_key)
+    assert np.array_equal(low, ref_low[env.local_slice()]) and np.array_equal(env.env.random_key, ref_env_key)
     q.put((rank, allr.tolist(), best))
     dist.barrier()
     dist.destroy_process_group()
@@ -74,26 +89,31 @@ def _pop_sharded_worker(rank, world, port, q, storage="bytes"):
     gm = synthetic_genetic_map(M, n_chr=2, seed=1)
     geno = synthetic_genotypes(N, M, seed=2).view(np.uint8)  # the whole population, known to the test only
     n_local = N // world
+    mine = slice(rank * n_local, (rank + 1) * n_local)
     sim = Simulator(genetic_map=gm, engine=OracleEngine(gm.recombination_vec, gm.marker_effects), seed=0)
-    rows = sim.engine.upload_population(geno[rank * n_local : (rank + 1) * n_local])
+    rows = sim.engine.upload_population(geno[mine])
     sp = ShardedPopulation(sim, rows, storage=storage)
     scores_all = co.gebv(geno, gm.marker_effects)[:, 0]
     scores_all[7] = scores_all[31] = scores_all[3]  # ties across shards resolve to the lower global index
+    scores_all[5] = scores_all[6]  # and inside a shard
     for k in (1, 5, 13, n_local, n_local + 4):
-        got = sp.global_topk(torch.from_numpy(scores_all[rank * n_local : (rank + 1) * n_local].copy()), k)
+        got = sp.global_topk(torch.from_numpy(scores_all[mine].copy()), k)
         assert np.array_equal(got.numpy(), co.topk(scores_all, k)), k
     best = sp.global_topk(sp.gebv()[:, 0], 9)
     parents = sp.gather_rows(best)
     assert np.array_equal(parents.numpy()[:, : 2 * M].reshape(9, M, 2), geno[best.numpy()])
-    # one full generation: every rank crosses its shard from the replicated winners
-    pairs = torch.from_numpy(np.random.default_rng(rank).integers(0, 9, (n_local, 2), dtype=np.int32))
-    key = co.key_from_seed(100 + rank).copy()
-    g = sp.select_and_cross(9, pairs, key)
-    true_best = co.topk(co.gebv(geno, gm.marker_effects)[:, 0], 9)
-    ref, refkey = co.cross(geno[true_best][None], pairs.numpy()[None], gm.recombination_vec,
-                           co.key_from_seed(100 + rank), 1)
-    assert np.array_equal(sp.rows.numpy()[:, : 2 * M].reshape(n_local, M, 2), ref[0])
-    assert np.array_equal(key, refkey) and np.allclose(np.asarray(g), co.gebv(ref[0], gm.marker_effects))
+    # WORLD-SIZE INVARIANCE over two generations: the same key on every rank, every rank's rows of one global
+    # pair table -> the generation one device would compute for the whole population, row for row
+    key = co.key_from_seed(100).copy()
+    ref, refkey = geno, co.key_from_seed(100)
+    for gen in range(2):
+        pairs_global = np.random.default_rng(gen).integers(0, 9, (N, 2), dtype=np.int32)
+        g = sp.select_and_cross(9, torch.from_numpy(pairs_global[mine]), key)
+        true_best = co.topk(co.gebv(ref, gm.marker_effects)[:, 0], 9)
+        out, refkey = co.cross(ref[true_best][None], pairs_global[None], gm.recombination_vec, refkey, 1)
+        ref = out[0]
+        assert np.array_equal(sp.rows.numpy()[:, : 2 * M].reshape(n_local, M, 2), ref[mine]), (rank, gen)
+        assert np.array_equal(key, refkey) and np.allclose(np.asarray(g), co.gebv(ref[mine], gm.marker_effects))
     q.put((rank, best.tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -116,8 +136,9 @@ def _run(worker, world=2, extra=()):
 
 
 @pytest.mark.timeout(180)
-def test_env_sharded_two_ranks():
-    out = _run(_env_sharded_worker)
+@pytest.mark.parametrize("env_rng", ["shared", "independent"])
+def test_env_sharded_two_ranks(env_rng):
+    out = _run(_env_sharded_worker, extra=(env_rng,))
     assert out[0][1] == out[1][1]  # every rank sees the same gathered rewards
     assert out[0][2] == out[1][2]
 

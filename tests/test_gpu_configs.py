@@ -336,3 +336,81 @@ def test_wheat_breed_gym_on_device_equals_oracle(small):  # breeding_programs_en
         p = u8(pd_)
         if not td.all():
             assert np.array_equal(p[..., 0], p[..., 1])  # every kept plant is a doubled haploid
+
+
+# ---- sharding windows: N shards compute what one device would -----------------------------
+
+
+@pytest.mark.parametrize("layout", ["original", "partitionable"])
+def test_sharding_windows_on_device(layout, rng):
+    """Two shards played one after the other on one GPU, each through its window: founder draws and selection
+    shuffles (env window), independent-key crosses of env shards (env window) and of one row-sharded batch (cross
+    window, byte layout and bit planes, over generations so that masks made ahead are used) -- all equal to the
+    oracle's result for the WHOLE, cut at the shard boundary."""
+    from breedgym_amd import HipEngine
+
+    co.set_threefry_layout(layout)
+    try:
+        M, N, E, n = 777, 50, 6, 10
+        r = (rng.random(M) * 0.05).astype(np.float32)
+        r[0] = 0.5
+        eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+        geno = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)
+        f_ref, key_ref = co.founders(co.key_from_seed(3), E, N, n)
+        scores = rng.standard_normal((E, n)).astype(np.float32)
+        a_ref, akey_ref = co.selection_actions(scores, 4, 5, co.key_from_seed(4))
+        pool = geno[f_ref]  # (E, n, M, 2)
+        idx = rng.integers(0, n, (E, n, 2), dtype=np.int32)
+        x_ref, xkey_ref = [], co.key_from_seed(6)
+        cur = pool
+        for gen in range(3):
+            cur, xkey_ref = co.cross(cur, idx, r, xkey_ref, 1)
+            x_ref.append(cur)
+        for shard, (lo, hi) in enumerate(((0, 2), (2, 6))):  # uneven shards
+            eng = HipEngine(r, eff, threefry_layout=layout)
+            eng.set_env_window(lo, E)
+            f, k = eng.founders(co.key_from_seed(3), hi - lo, N, n)
+            assert np.array_equal(f.cpu().numpy().reshape(hi - lo, n), f_ref[lo:hi]) and np.array_equal(k, key_ref)
+            a, k = eng.selection_actions(torch.from_numpy(scores[lo:hi]).to(eng.device), 4, 5, co.key_from_seed(4))
+            assert np.array_equal(a.cpu().numpy(), a_ref[lo:hi]) and np.array_equal(k, akey_ref)
+            rows = eng.upload_population(pool[lo:hi].reshape(-1, M, 2))
+            d_idx = torch.from_numpy(idx[lo:hi].copy()).to(eng.device)
+            key = co.key_from_seed(6).copy()
+            for gen in range(3):
+                out = eng.empty_population((hi - lo) * n)
+                eng.cross(rows, hi - lo, n, d_idx, n, key, 1, out, None)
+                got = eng.download_population(out).view(np.uint8).reshape(hi - lo, n, M, 2)
+                assert np.array_equal(got, x_ref[gen][lo:hi]), (shard, gen)
+                rows = out
+            assert np.array_equal(key, xkey_ref)
+        # one batch of crosses cut row-wise (population-sharded), bit planes, double haploid as well
+        k_win, n_total = 12, 40
+        winners = geno[:k_win]
+        pairs = rng.integers(0, k_win, (n_total, 2), dtype=np.int32)
+        for mode in (1, 3):
+            pr = pairs if mode == 1 else np.repeat(pairs[:, :1], 2, axis=1)
+            refs, kref = [], co.key_from_seed(8)
+            for gen in range(2):
+                o, kref = co.cross(winners[None], pr[None], r, kref, mode)
+                refs.append(o[0])
+            for lo, hi in ((0, 16), (16, 40)):
+                eng = HipEngine(r, eff, threefry_layout=layout)
+                eng.set_cross_window(lo, n_total)
+                wrows = eng.upload_population(winners)
+                wp = eng.pack(wrows)
+                d_idx = torch.from_numpy(pr[lo:hi].copy()).to(eng.device).reshape(1, -1, 2)
+                kb, kp = co.key_from_seed(8).copy(), co.key_from_seed(8).copy()
+                for gen in range(2):
+                    out, outp = eng.empty_population(hi - lo), eng.empty_packed(hi - lo)
+                    g = eng.empty((hi - lo, 1), torch.float32)
+                    eng.cross(wrows, 1, k_win, d_idx, hi - lo, kb, mode, out, g)
+                    eng.cross_packed(wp, 1, k_win, d_idx, hi - lo, kp, mode, outp, None, g)
+                    assert np.array_equal(eng.download_population(out).view(np.uint8), refs[gen][lo:hi]), (mode, lo, gen)
+                    assert np.array_equal(eng.download_population(eng.unpack(outp)).view(np.uint8), refs[gen][lo:hi])
+                    assert gebv_close(g.cpu().numpy(), co.gebv(refs[gen][lo:hi], eff, want64=True)[1])
+                assert np.array_equal(kb, kref) and np.array_equal(kp, kref)
+        with pytest.raises(ValueError):
+            eng.cross(wrows, 1, k_win, torch.zeros((1, 30, 2), dtype=torch.int32, device=eng.device), 30, kb, 1,
+                      eng.empty_population(30), None)  # 30 crosses at offset 16 exceed the window of 40
+    finally:
+        co.set_threefry_layout("original")
