@@ -97,6 +97,8 @@ struct bh_ctx {
   int64_t primed_envs = 0;
   bool big_lds_set = false;
   bool select_lds_set = false;
+  // device-side error word: host memory the kernels can write (a hand-off wait that ran out, row_kernels.h)
+  uint32_t *h_err = nullptr, *d_err = nullptr;
 };
 
 namespace {
@@ -179,6 +181,7 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
   m.key1 = key1;
   m.nkeys = (uint32_t)(dh ? kw.total + 1 : 2 * kw.total + 1);
   m.key_offset = (uint32_t)kw.off;
+  m.err = c->d_err;
   m.dh = dh;
   m.layout = c->layout;
   return m;
@@ -531,6 +534,12 @@ int check_ctx(const bh_ctx *c) {
   if (!c) return fail(BH_ERR_BAD_ARG, "null context");
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(BH_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+  if (c->h_err) {
+    const uint32_t w = *static_cast<volatile uint32_t *>(c->h_err);
+    if (w)
+      return fail(BH_ERR_HIP, "an earlier launch reported a device-side error (code %u: a mask hand-off wait ran out); "
+                              "its crossover masks, and every result since, are not to be trusted", w);
+  }
   return BH_OK;
 }
 
@@ -538,7 +547,7 @@ int check_ctx(const bh_ctx *c) {
 
 extern "C" {
 
-const char *bh_version(void) { return "breedhip 0.1.0 (gfx950)"; }
+const char *bh_version(void) { return "breedhip 0.2.0 (gfx950)"; }
 const char *bh_last_error(void) { return g_err; }
 
 int bh_device_count(int *count) {
@@ -626,6 +635,9 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
       return cleanup(fail(e_ == hipErrorOutOfMemory ? BH_ERR_OOM : BH_ERR_HIP, "%s failed: %s", \
                           #call, hipGetErrorString(e_)));                                       \
   } while (0)
+  BH_HIP_C(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(uint32_t), hipHostMallocMapped));
+  *c->h_err = 0u;
+  BH_HIP_C(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_err), c->h_err, 0));
   BH_HIP_C(hipMalloc(&c->d_thrA, nthr * sizeof(uint32_t)));
   BH_HIP_C(hipMalloc(&c->d_thrB, nthr * sizeof(uint32_t)));
   BH_HIP_C(hipMalloc(&c->d_eff, eff.size() * sizeof(double)));
@@ -755,6 +767,7 @@ int bh_destroy(bh_ctx *c) {
   (void)hipSetDevice(c->device);
   for (int i = 0; i < 2; ++i)
     if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
+  if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
   if (c->d_ctrB) (void)hipFree(c->d_ctrB);
@@ -786,7 +799,7 @@ int bh_set_stream(bh_ctx *c, void *hip_stream) {
 int bh_sync(bh_ctx *c) {
   if (int rc = check_ctx(c)) return rc;
   BH_HIP(hipStreamSynchronize(c->stream));
-  return BH_OK;
+  return check_ctx(c);  // ... and whatever the launches that just finished had to report
 }
 
 int64_t bh_row_pitch(const bh_ctx *c) { return c ? c->pitch : 0; }

@@ -51,6 +51,7 @@ struct MaskParams {
   uint32_t nkeys;       // keys split off it: 2*B + 1, or B + 1 for double haploids
   int32_t dh;           // 1: both gametes of cross c use keys[1 + c] (one gamete, doubled)
   int32_t layout;       // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE (threefry.h)
+  uint32_t *err;        // device-visible error word (host memory): a hand-off wait that ran out sets a bit
   uint32_t key_offset;  // cross c of this call is cross key_offset + c of the whole (sharded) batch the keys are
                         // split for: nkeys counts that whole batch (bh_set_cross_window)
 };
@@ -287,10 +288,17 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   const KeySched ka = key_sched(rk00, rk01), kb = key_sched(rk10, rk11);
   if constexpr (SYNC == SYNC_COUNTER) {
     if (iter > 0) {  // the previous cross's prefix pass must be through with the site words
+      bool ok = false;
       for (int spin = 0; spin < (1 << 24); ++spin) {
-        if (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)iter) break;
+        if (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)iter) {
+          ok = true;
+          break;
+        }
         __builtin_amdgcn_s_sleep(2);
       }
+      // all waves of a workgroup are resident, so the wait is finite; should it run out all the same, the
+      // masks are not to be trusted: say so where the host looks (check_ctx, bh_sync)
+      if (!ok && lane == 0 && p.err) __hip_atomic_fetch_or(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 
@@ -439,11 +447,15 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     // for wave 0, so the wait below always ends; it is bounded all the same
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (wv != 0) return;
+    bool ok = false;
     for (int spin = 0; spin < (1 << 24); ++spin) {
-      if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)(WAVES * (iter + 1)))
+      if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)(WAVES * (iter + 1))) {
+        ok = true;
         break;
+      }
       __builtin_amdgcn_s_sleep(2);
     }
+    if (!ok && lane == 0 && p.err) __hip_atomic_fetch_or(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 
   // ---- phase B: crossover masks = inclusive prefix-XOR of the site strings
