@@ -142,15 +142,16 @@ def time_events(launch, reps, warm=5):
     return ev0.elapsed_time(ev1) / reps
 
 
-def time_cross_launches(env, actions, reps):
+def time_cross_launches(env, actions, reps, with_gebv=True):
     """The hot-path launch alone (the fused two-role launch: streams this generation, makes the next
     one's masks), in the env's own storage layout, through the same C entry point the env uses but
-    without the reward reduction and the reset."""
+    without the reward reduction and the reset.  ``with_gebv=False`` leaves the GEBV out: where it is a
+    pass of its own (long rows, three traits and more) that isolates the cross launch."""
     import torch
 
     eng = env.simulator.engine
     E, n = env.num_envs, env._n
-    gebv = eng.empty((E, n, eng.n_traits), torch.float32)
+    gebv = eng.empty((E, n, eng.n_traits), torch.float32) if with_gebv else None
     key = np.ascontiguousarray(env.simulator.random_key.copy())
     if env.storage == "bits":
         pool, outp = env._prows, eng.empty_packed(E * n)
@@ -191,7 +192,7 @@ def committed_traffic(kernel_prefix):
     return None, "none: no committed PMC pass for this kernel"
 
 
-def bench_c3(steps, warmup, barrier):
+def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
     """BASELINE configs[2]: 2048 x 100k germplasm, 4 envs x 2048 = 8192 crosses per step, defaults."""
     import torch
 
@@ -205,17 +206,23 @@ def bench_c3(steps, warmup, barrier):
                        "every step, 10-generation episodes with autoreset, shared keys, bit-plane state"}
     arng = np.random.default_rng(3)
     for name, obs in (("eager", "eager"), ("lazy_observations", "lazy")):
+        if name not in variants:
+            continue
         env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, num_generations=N_GENERATIONS,
                           autoreset=True, reward_shaping=True, sync_rewards=False, genetic_map=gm, observations=obs)
         actions = [torch.from_numpy(arng.integers(0, n, (E, n, 2), dtype=np.int32)).to(env.device) for _ in range(4)]
         env.reset(seed=7)
         dt, _ = time_steps(env, actions, steps, warmup, barrier)
-        kms = time_cross_launches(env, actions, max(10, steps))
+        kms_all = time_cross_launches(env, actions, max(10, steps))
+        kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False)
         nbytes = cross_bytes(M, E * n, n, "bits", obs)
         r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
-             "roofline": roofline_of("packed_cross_kernel<1,4,2>", nbytes, kms,
+             "roofline": roofline_of("packed_cross_kernel<0,4,1> (long rows: the stream without GEBV; mask role: 2048 "
+                                     "keyed crosses x 100k markers of Threefry, the VALU floor of this launch)", nbytes, kms,
                                      api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
-             "step_frac_of_hbm_peak": nbytes / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
+             "gebv_pass_ms": kms_all - kms,
+             "gebv_pass_note": "gebv_bits_kernel + gebv_finish_kernel over the bit-plane offspring (0.2 GB)",
+             "step_frac_of_hbm_peak": (nbytes + E * n * packed_pitch(M)) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
         if name == "eager":
             out.update(r)
         else:
@@ -321,8 +328,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline configuration: no CPU leg, no other key mode / storage / config lines "
                          "(profiling runs, so that a kernel name in the profile is one configuration)")
-    ap.add_argument("--only", choices=("c3", "c5"), default=None,
-                    help="run only that extra configuration (profiling runs)")
+    ap.add_argument("--only", choices=("c3", "c3lazy", "c5"), default=None,
+                    help="run only that extra configuration (profiling runs: one configuration per kernel name)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -356,8 +363,9 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         return
-    if args.only == "c3":
-        print(json.dumps({"configs": {"c3": bench_c3(max(10, args.steps // 10), max(3, args.warmup // 10), barrier)}}))
+    if args.only in ("c3", "c3lazy"):
+        v = ("eager",) if args.only == "c3" else ("lazy_observations",)
+        print(json.dumps({"configs": {"c3": bench_c3(max(10, args.steps // 10), max(3, args.warmup // 10), barrier, v)}}))
         return
     if args.only == "c5":
         print(json.dumps({"configs": {"c5": bench_c5(max(20, args.steps // 4))}}))

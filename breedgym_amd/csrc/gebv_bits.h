@@ -58,14 +58,17 @@ __device__ __forceinline__ i32x4 dosage16_from_bits(uint32_t x) {
 template <int NT, int F>
 __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) {
   static_assert(NT == 1 || NT == 2, "one or two 32-column tiles");
-  constexpr int STEP_V = NT * 4 * 64;  // i32x4 per step in LDS
-  __shared__ i32x4 ldsB[2][STEP_V];
+  // a stage = the digit operands of QS steps (8 KB): with one column tile a step is only four MFMAs per tile,
+  // too little between two barriers
+  constexpr int QS = NT == 1 ? 2 : 1;
+  constexpr int STAGE_V = NT * QS * 256;  // i32x4 per stage in LDS
+  __shared__ i32x4 ldsB[2][STAGE_V];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int slice = blockIdx.y;
   const int mc_begin = slice * p.mc_per_slice;
   const int mc_end = min(p.n_mc, mc_begin + p.mc_per_slice);
-  const int n_steps = (mc_end - mc_begin) * 4;  // > 0 by construction of the grid
+  const int n_stages = (mc_end - mc_begin) * (4 / QS);  // > 0 by construction of the grid
 
   // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row
   // (its lanes re-read the last row; nothing of it is used by gebv_finish_kernel)
@@ -104,25 +107,27 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
         c.g[f][q] = in ? *reinterpret_cast<const uint4 *>(pa[f] + (int64_t)mc * 128 + 16 * q) : make_uint4(0, 0, 0, 0);
       }
   };
-  // digit operands of step k of this slice -> registers (NT 16-byte pieces per thread)
-  i32x4 breg[NT];
+  // digit operands of stage k of this slice -> registers (NT * QS 16-byte pieces per thread)
+  i32x4 breg[NT * QS];
   auto load_b = [&](int k) {
-    if (k < n_steps) {
-      const i32x4 *src = p.B + ((int64_t)(mc_begin * 4 + k) * 2) * 256;
+    if (k < n_stages) {
+      const i32x4 *src = p.B + ((int64_t)(mc_begin * 4 + k * QS) * 2) * 256;
 #pragma unroll
-      for (int u = 0; u < NT; ++u) breg[u] = src[u * 256 + tid];
+      for (int u = 0; u < QS; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) breg[u * NT + t] = src[(u * 2 + t) * 256 + tid];
     }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < NT; ++u) ldsB[buf][u * 256 + tid] = breg[u];
+    for (int u = 0; u < NT * QS; ++u) ldsB[buf][u * 256 + tid] = breg[u];
   };
-  auto step = [&](int buf, const Chunk &c, int q) {
+  auto step = [&](int buf, int u, const Chunk &c, int q) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       i32x4 b[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = ldsB[buf][(t * 4 + j) * 64 + lane];
+      for (int t = 0; t < NT; ++t) b[t] = ldsB[buf][(u * NT + t) * 256 + j * 64 + lane];
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         const uint4 g = c.g[f][q];
@@ -131,6 +136,16 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[f][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t], acc[f][t], 0, 0, 0);
       }
+    }
+  };
+  auto chunk_stages = [&](int &k, const Chunk &c) {
+#pragma unroll
+    for (int qq = 0; qq < 4 / QS; ++qq, ++k) {
+      store_b((k + 1) & 1);  // stage k+1's digits; that buffer was last read in stage k-1, before the barrier
+      load_b(k + 2);
+#pragma unroll
+      for (int u = 0; u < QS; ++u) step(k & 1, u, c, qq * QS + u);
+      __syncthreads();
     }
   };
 
@@ -143,22 +158,10 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
   int k = 0;
   for (int mc = mc_begin; mc < mc_end; mc += 2) {
     load_chunk(mc + 1, c1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q, ++k) {
-      store_b((k + 1) & 1);  // step k+1's digits; that buffer was last read in step k-1, before the barrier
-      load_b(k + 2);
-      step(k & 1, c0, q);
-      __syncthreads();
-    }
+    chunk_stages(k, c0);
     if (mc + 1 < mc_end) {
       load_chunk(mc + 2, c0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q, ++k) {
-        store_b((k + 1) & 1);
-        load_b(k + 2);
-        step(k & 1, c1, q);
-        __syncthreads();
-      }
+      chunk_stages(k, c1);
     }
   }
 

@@ -377,30 +377,36 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
 #else
 #define BH_TLOAD(r_, v_, s_) __builtin_amdgcn_raw_buffer_load_b32(r_, v_, s_, 0)
 #endif
+#ifndef BH_MASK_NPF  // trips whose tables are requested ahead (tuning experiments only)
+#define BH_MASK_NPF 4
+#endif
+  constexpr int NPF = BH_MASK_NPF;
   if (p.layout == LAYOUT_PARTITIONABLE)
   {
     int t = wv;
     uint32_t j = (uint32_t)wv * 64u + lane;
     uint32_t soff = (uint32_t)wv * 256u;
     constexpr uint32_t STEP = 256u * WAVES;
-    uint32_t tA0 = BH_TLOAD(rA, voff, soff);
-    uint32_t tB0 = BH_TLOAD(rB, voff, soff);
-    uint32_t cB0 = BH_TLOAD(rC, voff, soff);
-    uint32_t tA1 = BH_TLOAD(rA, voff, soff + STEP);
-    uint32_t tB1 = BH_TLOAD(rB, voff, soff + STEP);
-    uint32_t cB1 = BH_TLOAD(rC, voff, soff + STEP);
+    // the tables of NPF trips ahead are in flight: next to row waves that keep the memory pipeline full a load
+    // waits its turn for microseconds (profiles/r02_exp_c3_roles_pmc_priorities.txt)
+    uint32_t tA[NPF], tB[NPF], cB[NPF];
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      tA[u] = BH_TLOAD(rA, voff, soff + (uint32_t)u * STEP);
+      tB[u] = BH_TLOAD(rB, voff, soff + (uint32_t)u * STEP);
+      cB[u] = BH_TLOAD(rC, voff, soff + (uint32_t)u * STEP);
+    }
     while (t < p.nwh) {
-      BH_TRIP_P(t, j, tA0, tB0, cB0)
-      tA0 = BH_TLOAD(rA, voff, soff + 2u * STEP);
-      tB0 = BH_TLOAD(rB, voff, soff + 2u * STEP);
-      cB0 = BH_TLOAD(rC, voff, soff + 2u * STEP);
-      if (t + WAVES < p.nwh) BH_TRIP_P(t + WAVES, j + 64u * WAVES, tA1, tB1, cB1)
-      tA1 = BH_TLOAD(rA, voff, soff + 3u * STEP);
-      tB1 = BH_TLOAD(rB, voff, soff + 3u * STEP);
-      cB1 = BH_TLOAD(rC, voff, soff + 3u * STEP);
-      t += 2 * WAVES;
-      j += 128u * WAVES;
-      soff += 2u * STEP;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        if (u == 0 || t + u * WAVES < p.nwh) BH_TRIP_P(t + u * WAVES, j + 64u * (uint32_t)(u * WAVES), tA[u], tB[u], cB[u])
+        tA[u] = BH_TLOAD(rA, voff, soff + (uint32_t)(NPF + u) * STEP);
+        tB[u] = BH_TLOAD(rB, voff, soff + (uint32_t)(NPF + u) * STEP);
+        cB[u] = BH_TLOAD(rC, voff, soff + (uint32_t)(NPF + u) * STEP);
+      }
+      t += NPF * WAVES;
+      j += 64u * (uint32_t)(NPF * WAVES);
+      soff += (uint32_t)NPF * STEP;
     }
   }
   else
@@ -409,24 +415,26 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     uint32_t j = (uint32_t)wv * 64u + lane;
     uint32_t soff = (uint32_t)wv * 256u;
     constexpr uint32_t STEP = 256u * WAVES;
-    uint32_t tA0 = BH_TLOAD(rA, voff, soff);
-    uint32_t tB0 = BH_TLOAD(rB, voff, soff);
-    uint32_t cB0 = BH_TLOAD(rC, voff, soff);
-    uint32_t tA1 = BH_TLOAD(rA, voff, soff + STEP);
-    uint32_t tB1 = BH_TLOAD(rB, voff, soff + STEP);
-    uint32_t cB1 = BH_TLOAD(rC, voff, soff + STEP);
+    // the tables of NPF trips ahead are in flight: next to row waves that keep the memory pipeline full a load
+    // waits its turn for microseconds (profiles/r02_exp_c3_roles_pmc_priorities.txt)
+    uint32_t tA[NPF], tB[NPF], cB[NPF];
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      tA[u] = BH_TLOAD(rA, voff, soff + (uint32_t)u * STEP);
+      tB[u] = BH_TLOAD(rB, voff, soff + (uint32_t)u * STEP);
+      cB[u] = BH_TLOAD(rC, voff, soff + (uint32_t)u * STEP);
+    }
     while (t < p.nwh) {
-      BH_TRIP(t, j, tA0, tB0, cB0)
-      tA0 = BH_TLOAD(rA, voff, soff + 2u * STEP);
-      tB0 = BH_TLOAD(rB, voff, soff + 2u * STEP);
-      cB0 = BH_TLOAD(rC, voff, soff + 2u * STEP);
-      if (t + WAVES < p.nwh) BH_TRIP(t + WAVES, j + 64u * WAVES, tA1, tB1, cB1)
-      tA1 = BH_TLOAD(rA, voff, soff + 3u * STEP);
-      tB1 = BH_TLOAD(rB, voff, soff + 3u * STEP);
-      cB1 = BH_TLOAD(rC, voff, soff + 3u * STEP);
-      t += 2 * WAVES;
-      j += 128u * WAVES;
-      soff += 2u * STEP;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        if (u == 0 || t + u * WAVES < p.nwh) BH_TRIP(t + u * WAVES, j + 64u * (uint32_t)(u * WAVES), tA[u], tB[u], cB[u])
+        tA[u] = BH_TLOAD(rA, voff, soff + (uint32_t)(NPF + u) * STEP);
+        tB[u] = BH_TLOAD(rB, voff, soff + (uint32_t)(NPF + u) * STEP);
+        cB[u] = BH_TLOAD(rC, voff, soff + (uint32_t)(NPF + u) * STEP);
+      }
+      t += NPF * WAVES;
+      j += 64u * (uint32_t)(NPF * WAVES);
+      soff += (uint32_t)NPF * STEP;
     }
   }
 #undef BH_TRIP

@@ -1,0 +1,70 @@
+"""Distil gpurun_out/prof_r02/ (tools/collect_profiles_r02.sh, run on the GPU box) into the committed files under
+profiles/: r02_kernel_stats_{c2,c3,c5}.csv, r02_pmc.json and r02_pmc_traffic.json (per-kernel HBM-side bytes per
+launch, corrected as MI355X_MICROARCH.md prescribes; bench.py names it as the source of roofline.traffic)."""
+import csv
+import glob
+import json
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+src, dst = ROOT / "gpurun_out" / "prof_r02", ROOT / "profiles"
+
+
+def newest(pattern):
+    f = sorted(glob.glob(str(src / pattern), recursive=True), key=lambda x: Path(x).stat().st_mtime)
+    return f[-1] if f else None
+
+
+def short(name):
+    return name.split("(")[0].replace("void bh::", "").replace("bh::", "")
+
+
+for cfg in ("c2", "c3", "c3lazy", "c5"):
+    f = newest(f"kt_{cfg}/**/*kernel_stats.csv")
+    if f:
+        rows = list(csv.DictReader(open(f)))
+        with open(dst / f"r02_kernel_stats_{cfg}.csv", "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(rows)
+        print(cfg, *(f"{short(r['Name'])[:60]:60s} calls={r['Calls']:>5s} avg={float(r['AverageNs'])/1e3:9.2f} us" for r in rows[:6]), sep="\n  ")
+
+
+def counters(sub):
+    f = newest(f"{sub}/**/*counter_collection.csv")
+    out = {}
+    if not f:
+        return out
+    acc = defaultdict(lambda: defaultdict(list))
+    disp = defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        disp[k].add(r["Dispatch_Id"])
+    for k, d in acc.items():
+        out[k] = {c: sum(v) / len(v) for c, v in d.items()}
+        out[k]["dispatches"] = len(disp[k])
+    return out
+
+
+pmc = {f"{kind}_{cfg}": counters(f"{kind}_{cfg}") for cfg in ("c2", "c3", "c5") for kind in ("fetch", "write", "sq")}
+(dst / "r02_pmc.json").write_text(json.dumps(pmc, indent=1, sort_keys=True))
+
+# HBM-side bytes per launch: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
+# wide coalesced (16 B/lane) streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane stores.  The 2-byte genotype
+# words and 4-byte table loads of these kernels are widths the guide has not calibrated (small next to the stores).
+kernels = []
+for cfg in ("c2", "c3", "c5"):
+    for k, d in pmc[f"fetch_{cfg}"].items():
+        if not any(t in k for t in ("packed_cross_kernel", "gebv_bits_kernel", "gebv_finish_kernel", "gebv_mfma_kernel")):
+            continue
+        fk = d.get("FETCH_SIZE", 0.0)
+        wk = pmc[f"write_{cfg}"].get(k, {}).get("WRITE_SIZE", 0.0)
+        kernels.append({"config": cfg, "kernel": k, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
+                        "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "dispatches": d.get("dispatches")})
+(dst / "r02_pmc_traffic.json").write_text(json.dumps({
+    "correction": "2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (MI355X_MICROARCH.md, HBM); separate --pmc passes",
+    "made_by": "tools/collect_profiles_r02.sh + tools/distil_profiles_r02.py", "kernels": kernels}, indent=1))
+for k in kernels:
+    print(f"{k['config']} {k['kernel'][:50]:50s} {k['hbm_bytes_per_launch']/1e6:10.1f} MB per launch")
