@@ -65,6 +65,8 @@ struct bh_ctx {
   // masks of generation g+1 in d_Z[1 - cur] (cross_kernel's two roles)
   uint8_t *d_Z[2] = {nullptr, nullptr};
   int64_t z_cap[2] = {0, 0};  // bytes
+  uint64_t *d_S = nullptr;    // site words of the stream-per-lane mask role (mask_stream.h)
+  int64_t s_cap = 0;          // bytes
   bool prefetch = true;
   int layout = bh::LAYOUT_ORIGINAL;  // bh_set_threefry_layout
   // sharding windows: this context holds envs [env_offset, env_offset + n_envs) of envs_total, or crosses
@@ -271,11 +273,37 @@ template <int TT, int MW, int R>
 int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   const int per_wave = R * std::max(1, rp.seq);
   rp.n_blocks = (rp.n_rows + 4 * per_wave - 1) / (4 * per_wave);
-  const size_t lds = (size_t)mp.group_lds * (4 / MW);
-  const int grid = MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks);
+  // stream-per-lane mask role: no LDS, its waves share the mask work whatever the grid is
+  const size_t lds = mp.sites ? 0 : (size_t)mp.group_lds * (4 / MW);
+  const int grid = mp.sites ? rp.n_blocks
+                            : (MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks));
   hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
+  if (mp.sites) {  // site words -> crossover masks, one wave per keyed cross
+    hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((mp.n_rows + 3) / 4)), dim3(256), 0, c->stream, mp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_finish_kernel launch: %s", hipGetErrorString(e));
+  }
+  return BH_OK;
+}
+
+// the launch for many long rows: stream role in turns + stream-per-lane mask role, then the site words -> masks
+#ifndef BH_LONG_MASK_WAVES  // mask waves per workgroup of four row waves (tuning experiments only)
+#define BH_LONG_MASK_WAVES 8
+#endif
+int launch_plong(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
+  const int per_wave = kRowsPerWaveLong * std::max(1, rp.seq);
+  rp.n_blocks = (rp.n_rows + 4 * per_wave - 1) / (4 * per_wave);
+  hipLaunchKernelGGL((bh::packed_long_kernel<kRowsPerWaveLong, BH_LONG_MASK_WAVES>), dim3((unsigned)rp.n_blocks),
+                     dim3(64 * (4 + BH_LONG_MASK_WAVES)), 0, c->stream, rp, mp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_long_kernel launch: %s", hipGetErrorString(e));
+  // site words -> masks, one wave per keyed cross, in stream order (a stream of its own beside the GEBV pass
+  // that follows was measured: 811 against 818 us per step at 8192 x 100k -- both want the same memory system)
+  hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((mp.n_rows + 3) / 4)), dim3(256), 0, c->stream, mp);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_finish_kernel launch: %s", hipGetErrorString(e));
   return BH_OK;
 }
 
@@ -343,6 +371,20 @@ int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
 int long_row_turns(const bh_ctx *c, int64_t rows) {
   if (c->M <= 16384 || rows < 2 * BH_LONG_STREAMS) return 0;
   return (int)std::min<int64_t>(16, rows / BH_LONG_STREAMS);
+}
+
+// site words of B crosses for mask_stream_role: (B, nwh + 1, 4) u64, zero where never written
+int ensure_sites(bh_ctx *c, int64_t B) {
+  const int64_t bytes = B * (c->nwh + 1) * 32;
+  if (c->s_cap >= bytes) return BH_OK;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_S) BH_HIP(hipFree(c->d_S));
+  c->d_S = nullptr;
+  c->s_cap = 0;
+  BH_HIP(hipMalloc(&c->d_S, (size_t)bytes));
+  BH_HIP(hipMemsetAsync(c->d_S, 0, (size_t)bytes, c->stream));
+  c->s_cap = bytes;
+  return BH_OK;
 }
 
 int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 ? 2 : tcount <= 4 ? 4 : 8; }
@@ -768,6 +810,7 @@ int bh_destroy(bh_ctx *c) {
   for (int i = 0; i < 2; ++i)
     if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
   if (c->h_err) (void)hipHostFree(c->h_err);
+  if (c->d_S) (void)hipFree(c->d_S);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
   if (c->d_ctrB) (void)hipFree(c->d_ctrB);
@@ -975,8 +1018,16 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
         if (mw == 1)
           rc = wide ? launch_pcross_mw<1, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<1, 1>(c, p, mp, tt_for(tcount));
-        else if (turns > 1)
+        else if (turns > 1) {
+#if !defined(BH_NO_MASK_STREAM)  // tuning experiments only: the LDS mask role next to the long-row stream
+          if (int rc2 = ensure_sites(c, B)) return rc2;
+          mp.sites = c->d_S;
+          mp.spitch = c->nwh + 1;
+          rc = launch_plong(c, p, mp);
+#else
           rc = launch_pcross_mw<4, kRowsPerWaveLong>(c, p, mp, 0);
+#endif
+        }
         else
           rc = wide ? launch_pcross_mw<4, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<4, 1>(c, p, mp, tt_for(tcount));

@@ -14,12 +14,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mask_stream.h"
 #include "row_kernels.h"
 
 namespace bh {
 
+#ifndef BH_LONG_ROW_PRIO  // priority of the row waves of the long-row stream (tuning experiments only)
+#define BH_LONG_ROW_PRIO 2
+#endif
 #ifndef BH_LONG_VPT  // vectors per lane and trip in the long-row stream (tuning experiments only)
-#define BH_LONG_VPT 2
+#define BH_LONG_VPT 4
 #endif
 constexpr int kLongRowVectors = BH_LONG_VPT;
 
@@ -213,9 +217,9 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   constexpr int NT = TT > 0 ? TT : 1;
   const int lane = threadIdx.x & 63;
   const int seq = p.seq > 1 ? p.seq : 1;
-#if defined(BH_LONG_ROW_PRIO)  // tuning experiments only
+  // without GEBV the stream is almost all memory instructions: above the mask waves it keeps the memory pipeline
+  // fed and they take every issue slot it leaves (their role has no vector loads to be starved of, mask_stream.h)
   if constexpr (TT == 0) __builtin_amdgcn_s_setprio(BH_LONG_ROW_PRIO);
-#endif
   const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R * seq);
   for (int sq = 0; sq < seq; ++sq) {
     const int c0 = first + sq * R;
@@ -288,6 +292,11 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         }
       }
     };
+#if defined(BH_LONG_AHEAD)  // trips the long-row stream requests ahead (tuning experiments only)
+    constexpr int AHEAD = TT == 0 ? BH_LONG_AHEAD : 1;
+#else
+    constexpr int AHEAD = 1;
+#endif
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
       const bool has = v < p.nvec;
@@ -309,7 +318,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
 #endif
         }
       }
-      load_words(base + 64 * VPT, next);
+      load_words(base + 64 * VPT * AHEAD, next);
       uint4 oo[R];
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -346,12 +355,23 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         }
       }
     };
-    Words wa, wb;
-    load_words(0, wa);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending (row_role_pipelined)
-    for (int base = 0; base < p.nvec; base += 128 * VPT) {  // two trips per turn, no branch between them
-      trip(base, wa, wb);
-      trip(base + 64 * VPT, wb, wa);
+    if constexpr (AHEAD == 1) {
+      Words wa, wb;
+      load_words(0, wa);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending (row_role_pipelined)
+      for (int base = 0; base < p.nvec; base += 128 * VPT) {  // two trips per turn, no branch between them
+        trip(base, wa, wb);
+        trip(base + 64 * VPT, wb, wa);
+      }
+    } else {  // two trips ahead: three register sets in rotation (trip t fills the set trip t + 2 reads)
+      Words wa, wb, wc;
+      load_words(0, wa);
+      load_words(64 * VPT, wb);
+      for (int base = 0; base < p.nvec; base += 192 * VPT) {
+        trip(base, wa, wc);
+        trip(base + 64 * VPT, wb, wa);
+        trip(base + 128 * VPT, wc, wb);
+      }
     }
     if (p.nvec + lane < p.nvp) {  // padding words: markers beyond M, up to the next multiple of 64
 #pragma unroll
@@ -449,9 +469,37 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
   } else if constexpr (MW == 1) {
     if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
   } else {
+    if (mp.sites) {  // long rows: one gamete stream per lane, site words to memory (mask_stream.h)
+      mask_stream_role(mp, (int)blockIdx.x * 4 + wave - 4, (int)gridDim.x * 4);
+      return;
+    }
     int iter = 0;  // crosses in turns when the grid is shorter than the mask work (cross_kernel)
     for (int mb = (int)blockIdx.x; mb < mp.n_blocks; mb += (int)gridDim.x, ++iter)
       mask_role<4, SYNC_COUNTER>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
+  }
+}
+
+// Many long rows (HBM-resident): four row waves stream rows in turns without GEBV (packed_stream_role, TT = 0),
+// MASK_WAVES waves draw the next generation's recombination sites one gamete stream per lane (mask_stream.h).
+// No LDS, no barrier; the two kinds of wave never wait for each other.  More mask waves than row waves: the
+// Threefry chains of a wave leave issue slots that only other waves can fill, and the workgroups of a grid of
+// rows / (4 R seq) are few enough to be resident all at once (no tail of late workgroups doing mask work alone).
+template <int R, int MASK_WAVES>
+__global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(const PackedParams rp, const MaskParams mp) {
+  prime_next_reward(rp.reward_next, rp.n_envs);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only
+  if (wave < 4) return;
+#elif defined(BH_ABLATE_NO_MASKROLE)
+  if (wave >= 4) return;
+#endif
+  if (wave < 4) {
+    if (rp.outb)
+      packed_stream_role<0, MODE_CROSS, R, true, kLongRowVectors>(rp, (int)blockIdx.x, wave);
+    else
+      packed_stream_role<0, MODE_CROSS, R, false, kLongRowVectors>(rp, (int)blockIdx.x, wave);
+  } else {
+    mask_stream_role(mp, (int)blockIdx.x * MASK_WAVES + wave - 4, (int)gridDim.x * MASK_WAVES);
   }
 }
 

@@ -30,6 +30,10 @@
 
 #include "threefry.h"
 
+#ifndef BH_MASK_PRIO  // priority of mask waves next to row waves (tuning experiments only)
+#define BH_MASK_PRIO 1
+#endif
+
 namespace bh {
 
 enum { MODE_CROSS = 0, MODE_GATHER = 1, MODE_GEBV = 2 };
@@ -51,6 +55,8 @@ struct MaskParams {
   uint32_t nkeys;       // keys split off it: 2*B + 1, or B + 1 for double haploids
   int32_t dh;           // 1: both gametes of cross c use keys[1 + c] (one gamete, doubled)
   int32_t layout;       // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE (threefry.h)
+  uint64_t *sites;      // mask_stream_role / mask_finish_kernel (mask_stream.h): (n_rows, spitch, 4) site words in
+  int32_t spitch;       // memory, spitch = nwh + 1 trips per cross (the last one stays zero); null: mask_role
   uint32_t *err;        // device-visible error word (host memory): a hand-off wait that ran out sets a bit
   uint32_t key_offset;  // cross c of this call is cross key_offset + c of the whole (sharded) batch the keys are
                         // split for: nkeys counts that whole batch (bh_set_cross_window)
@@ -256,9 +262,6 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   // four-wave groups run next to row waves at the default priority (few keyed crosses, the launch
   // is bound by the streaming): one step above them the mask role is out of the way sooner --
   // 1-5 % on most shapes, 11 % at 2200 x 16k markers, -2 % on one (profiles/r01_ab_mask_priority.txt)
-#ifndef BH_MASK_PRIO  // tuning experiments only
-#define BH_MASK_PRIO 1
-#endif
   if constexpr (SYNC == SYNC_COUNTER && BH_MASK_PRIO > 0) __builtin_amdgcn_s_setprio(BH_MASK_PRIO);
   uint64_t *S = reinterpret_cast<uint64_t *>(lds_raw + (size_t)grp * p.group_lds);  // [nwh + 1][4]
 

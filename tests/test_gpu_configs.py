@@ -414,3 +414,51 @@ def test_sharding_windows_on_device(layout, rng):
                       eng.empty_population(30), None)  # 30 crosses at offset 16 exceed the window of 40
     finally:
         co.set_threefry_layout("original")
+
+
+# ---- many long rows: the stream-per-lane mask role + mask_finish_kernel (csrc/mask_stream.h) --------------
+
+
+@pytest.mark.parametrize("layout", ["original", "partitionable"])
+@pytest.mark.parametrize("mode,M", [(0, 16523), (1, 16523), (2, 20000), (0, 50001)])
+def test_many_long_rows_stream_mask_role(layout, mode, M, rng):
+    """>= 8192 bit-plane rows of > 16384 markers: the launch streams rows in turns, draws the next generation's
+    recombination sites one gamete stream per lane (thresholds through the scalar cache) and a second kernel
+    turns the site words into masks.  Three generations (the last two read masks made that way), every offspring
+    against the oracle; odd M, a half that is no multiple of 64, always-recombining markers, all key modes."""
+    from breedgym_amd import HipEngine
+
+    co.set_threefry_layout(layout)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    try:
+        E, n, NP = (2, 4100, 37) if M < 30000 else (1, 8200, 29)
+        pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+        if mode & 2:
+            one = rng.integers(0, NP, (E, n), dtype=np.int32)
+            idx = np.stack((one, one), -1)
+        else:
+            idx = rng.integers(0, NP, (E, n, 2), dtype=np.int32)
+        r = (rng.random(M) * 0.004).astype(np.float32)
+        r[:: M // 21] = 0.5
+        r[rng.random(M) < 0.16] = 0.0
+        r[5], r[M // 2 + 3], r[M - 2] = 1.0, 2.0, 1.0
+        eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+        eng = HipEngine(r, eff, threefry_layout=layout)
+        packed = eng.pack(eng.upload_population(pool.reshape(E * NP, M, 2)))
+        d_idx = torch.from_numpy(idx).to(eng.device)
+        key, ref_key = co.key_from_seed(31).copy(), co.key_from_seed(31)
+        for gen in range(3):
+            outp = eng.empty_packed(E * n)
+            ob = eng.empty_population(E * n) if gen != 1 else None
+            g = eng.empty((E, n, 1), torch.float32)
+            eng.cross_packed(packed, E, NP, d_idx, n, key, mode, outp, ob, g)
+            ref, ref_key = co.cross(pool, idx, r, ref_key, mode)
+            got = eng.download_population(eng.unpack(outp)).view(np.uint8).reshape(ref.shape)
+            assert np.array_equal(got, ref), f"gen {gen}: {np.argwhere(got != ref)[:4]}"
+            if ob is not None:
+                assert np.array_equal(eng.download_population(ob).view(np.uint8).reshape(ref.shape), ref)
+            assert np.array_equal(key, ref_key)
+            assert gebv_close(g.cpu().numpy(), co.gebv(ref, eff, want64=True)[1])
+        eng.sync()
+    finally:
+        co.set_threefry_layout("original")
