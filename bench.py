@@ -217,8 +217,10 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
         kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False)
         nbytes = cross_bytes(M, E * n, n, "bits", obs)
         r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
-             "roofline": roofline_of("packed_cross_kernel<0,4,1> (long rows: the stream without GEBV; mask role: 2048 "
-                                     "keyed crosses x 100k markers of Threefry, the VALU floor of this launch)", nbytes, kms,
+             "roofline": roofline_of("packed_long_kernel<1,8> + mask_finish_kernel (long rows: four row waves stream rows "
+                                     "without GEBV, eight mask waves draw the next generation's sites one gamete stream "
+                                     "per lane -- 2048 keyed crosses x 100k markers of Threefry; then site words -> masks)",
+                                     nbytes + 2 * 4 * n * (M // 128 + 2) * 8, kms,  # + site words written and read back
                                      api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
              "gebv_pass_ms": kms_all - kms,
              "gebv_pass_note": "gebv_bits_kernel + gebv_finish_kernel over the bit-plane offspring (0.2 GB)",

@@ -113,6 +113,7 @@ SIGNATURES = {
     "bh_permutation": (_int, [_u32p, _i64, _int, _i32p]),
     "bh_founders": (_int, [_u32p, _i64, _i64, _i64, _int, _i32p]),
     "bh_founders_device": (_int, [_vp, _u32p, _i64, _i64, _i64, _vp]),
+    "bh_founders_deferred": (_int, [_vp, _u32p, _i64, _i64, _i64, _vp]),
 }
 
 

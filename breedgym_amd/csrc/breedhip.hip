@@ -94,6 +94,9 @@ struct bh_ctx {
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};
   int64_t cand_cap = 0;
+  // a founder draw asked for ahead (bh_founders_deferred): rides on the next two-role launch, or gets its own
+  bh::FoundersParams fp_pending{};
+  bool founders_pending = false;
   // reward chaining (bh_cross*): the buffer the last launch left holding -inf, ready to take atomic maxima
   const float *primed_reward = nullptr;
   int64_t primed_envs = 0;
@@ -274,10 +277,17 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   const int per_wave = R * std::max(1, rp.seq);
   rp.n_blocks = (rp.n_rows + 4 * per_wave - 1) / (4 * per_wave);
   // stream-per-lane mask role: no LDS, its waves share the mask work whatever the grid is
-  const size_t lds = mp.sites ? 0 : (size_t)mp.group_lds * (4 / MW);
-  const int grid = mp.sites ? rp.n_blocks
-                            : (MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks));
-  hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp);
+  size_t lds = mp.sites ? 0 : (size_t)mp.group_lds * (4 / MW);
+  int grid = mp.sites ? rp.n_blocks
+                      : (MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks));
+  bh::FoundersParams fp{};
+  if (MW == 4 && c->founders_pending && c->fp_pending.P <= 1024 && (size_t)c->fp_pending.P * 16 <= 48 * 1024) {
+    fp = c->fp_pending;  // the draw rides on this launch: E more workgroups
+    c->founders_pending = false;
+    grid += fp.E;
+    lds = std::max(lds, (size_t)fp.P * 16);
+  }
+  hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
   if (mp.sites) {  // site words -> crossover masks, one wave per keyed cross
@@ -572,6 +582,29 @@ int packed_gebv_chunks(bh_ctx *c, const uint16_t *d_rows, int64_t rows, float *d
   return BH_OK;
 }
 
+int launch_founders(bh_ctx *c, const bh::FoundersParams &p);
+
+// a deferred founder draw that found no launch to ride on is made now, in stream order
+int flush_founders(bh_ctx *c) {
+  if (!c->founders_pending) return BH_OK;
+  c->founders_pending = false;
+  return launch_founders(c, c->fp_pending);
+}
+
+int launch_founders(bh_ctx *c, const bh::FoundersParams &p) {
+  const size_t lds = (size_t)p.P * 16;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::founders_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(founders LDS): %s", hipGetErrorString(e));
+  }
+  const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, p.P / 2));
+  hipLaunchKernelGGL(bh::founders_kernel, dim3((unsigned)p.E), dim3(threads), lds, c->stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "founders_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
 int check_ctx(const bh_ctx *c) {
   if (!c) return fail(BH_ERR_BAD_ARG, "null context");
   hipError_t e = hipSetDevice(c->device);
@@ -841,6 +874,7 @@ int bh_set_stream(bh_ctx *c, void *hip_stream) {
 
 int bh_sync(bh_ctx *c) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   BH_HIP(hipStreamSynchronize(c->stream));
   return check_ctx(c);  // ... and whatever the launches that just finished had to report
 }
@@ -872,6 +906,7 @@ int bh_memcpy_h2d(bh_ctx *c, void *dst, const void *src, int64_t bytes) {
 
 int bh_memcpy_d2h(bh_ctx *c, void *dst, const void *src, int64_t bytes) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (bytes < 0 || (bytes > 0 && (!dst || !src))) return fail(BH_ERR_BAD_ARG, "bh_memcpy_d2h: bad arguments");
   if (bytes) BH_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
   BH_HIP(hipStreamSynchronize(c->stream));
@@ -898,6 +933,7 @@ int bh_upload_population(bh_ctx *c, const uint8_t *host, int64_t rows, uint8_t *
 
 int bh_download_population(bh_ctx *c, const uint8_t *d_src, int64_t rows, uint8_t *host) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (rows < 0 || (rows > 0 && (!host || !d_src))) return fail(BH_ERR_BAD_ARG, "bh_download_population: bad arguments");
   if (rows == 0) return BH_OK;
   const int64_t w = 2 * c->M;
@@ -1064,6 +1100,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       }
     }
     if (rc) return rc;
+    if (int rc2 = flush_founders(c)) return rc2;  // a deferred founder draw this kind of launch could not carry
     if (run_ahead) {
       c->pf.valid = true;
       c->pf.buf = 1 - buf;
@@ -1134,6 +1171,7 @@ int bh_pack(bh_ctx *c, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed
 int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
                      uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (n_rows < 0 || src_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: negative size");
   if (n_rows == 0) return BH_OK;
   if (!d_src) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: null device pointer");
@@ -1189,6 +1227,7 @@ int bh_set_mask_prefetch(bh_ctx *c, int enable) {
 int bh_gather(bh_ctx *c, const uint8_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
               uint8_t *d_out, float *d_gebv) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (n_rows < 0 || src_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gather: negative size");
   if (n_rows == 0) return BH_OK;
   if (!d_src || !d_idx || !d_out) return fail(BH_ERR_BAD_ARG, "bh_gather: null device pointer");
@@ -1212,6 +1251,7 @@ int bh_gather(bh_ctx *c, const uint8_t *d_src, int64_t src_rows, const int32_t *
 
 int bh_gebv(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gebv: negative size");
   if (rows == 0 || c->T == 0) return BH_OK;
   if (!d_pop || !d_gebv) return fail(BH_ERR_BAD_ARG, "bh_gebv: null device pointer");
@@ -1351,6 +1391,7 @@ int bh_topk(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t
 int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n, int64_t k, int64_t n_crosses,
                          uint32_t env_key[2], int32_t *d_actions) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (!env_key || n_envs < 0 || n <= 0) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: bad sizes");
   const int64_t n_pairs = k * (k - 1) / 2;
   if (k < 2 || k > n) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 2 <= k <= n");
@@ -1398,9 +1439,10 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
   return BH_OK;
 }
 
-int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
-                       int32_t *d_out) {
+static int founders_device_impl(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                                int32_t *d_out, bool defer) {
   if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
   if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !d_out))
     return fail(BH_ERR_BAD_ARG, "bh_founders_device: need 0 <= n <= n_germplasm");
   if (n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: too many envs");
@@ -1429,20 +1471,22 @@ int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n
       p.layout = c->layout;
       p.E_total = (int32_t)e_total;
       p.env_offset = (int32_t)e_off;
-      const size_t lds = (size_t)p.P * 16;
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::founders_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(founders LDS): %s", hipGetErrorString(e));
-      }
-      const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, p.P / 2));
-      hipLaunchKernelGGL(bh::founders_kernel, dim3((unsigned)n_envs), dim3(threads), lds, c->stream, p);
-      BH_HIP(hipGetLastError());
+      if (int rc = (defer ? (c->fp_pending = p, c->founders_pending = true, BH_OK) : launch_founders(c, p))) return rc;
     }
   }
   env_key[0] = nk.x;
   env_key[1] = nk.y;
   return BH_OK;
+}
+
+int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                       int32_t *d_out) {
+  return founders_device_impl(c, env_key, n_envs, n_germplasm, n, d_out, false);
+}
+
+int bh_founders_deferred(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                         int32_t *d_out) {
+  return founders_device_impl(c, env_key, n_envs, n_germplasm, n, d_out, true);
 }
 
 void bh_key_from_seed(uint64_t seed, uint32_t key[2]) {

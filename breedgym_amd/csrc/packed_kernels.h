@@ -26,6 +26,10 @@ namespace bh {
 #define BH_LONG_VPT 4
 #endif
 constexpr int kLongRowVectors = BH_LONG_VPT;
+#ifndef BH_SHORT_VPT  // ... and in the stream with GEBV (tuning experiments only)
+#define BH_SHORT_VPT 2
+#endif
+constexpr int kShortRowVectors = BH_SHORT_VPT;
 
 struct PackedParams {
   const uint16_t *src;  // cross: (E, n_pool, nvp) packed pool; gather: (n_pool, nvp)
@@ -213,7 +217,6 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
                                                    RewardLds *rw = nullptr) {
   static_assert(TT >= 0 && TT <= 2, "effects are held in registers across the trip");
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
-  static_assert(VPT == 1 || TT == 0, "several vectors per lane and trip only without GEBV in the stream");
   constexpr int NT = TT > 0 ? TT : 1;
   const int lane = threadIdx.x & 63;
   const int seq = p.seq > 1 ? p.seq : 1;
@@ -299,61 +302,60 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
 #endif
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
-      const bool has = v < p.nvec;
-      const int vv = v < last ? v : last;
-      uint4 dg[NT][3];
+      uint4 dg[VPT][NT][3];
       if constexpr (TT > 0) {
 #pragma unroll
-        for (int q = 0; q < TT; ++q) {
+        for (int u = 0; u < VPT; ++u) {
+          const int vu = v + 64 * u < last ? v + 64 * u : last;
+#pragma unroll
+          for (int q = 0; q < TT; ++q) {
 #if defined(BH_DIG_INTERLEAVED)  // tuning experiments only: digits of a vector side by side (lane stride 48 B)
-          const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
-          dg[q][0] = dp[0];
-          dg[q][1] = dp[1];
-          dg[q][2] = dp[2];
+            const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vu) * 3;
+            dg[u][q][0] = dp[0];
+            dg[u][q][1] = dp[1];
+            dg[u][q][2] = dp[2];
 #else  // one plane per digit: a wave's load is 1 KB contiguous
-          const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vv;
-          dg[q][0] = dp[0];
-          dg[q][1] = dp[p.nvec];
-          dg[q][2] = dp[2 * (int64_t)p.nvec];
+            const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vu;
+            dg[u][q][0] = dp[0];
+            dg[u][q][1] = dp[p.nvec];
+            dg[u][q][2] = dp[2 * (int64_t)p.nvec];
 #endif
+          }
         }
       }
       load_words(base + 64 * VPT * AHEAD, next);
-      uint4 oo[R];
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int u = 0; u < VPT; ++u) {
+          const bool has = v + 64 * u < p.nvec;
           const int vu = v + 64 * u < last ? v + 64 * u : last;
           uint32_t o = w.a[u][r];
           if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
-          oo[r] = expand_vector(o);
-          if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo[r];
-        }
-      if constexpr (TT > 0) {
-        if (has) {  // a lane that redid the last vector must not count it twice
-          typedef short short2v __attribute__((ext_vector_type(2)));
+          const uint4 oo = expand_vector(o);
+          if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo;
+          if constexpr (TT > 0) {
+            if (has) {  // a lane that redid the last vector must not count it twice
+              typedef short short2v __attribute__((ext_vector_type(2)));
+              const uint32_t ww[4] = {oo.x, oo.y, oo.z, oo.w};
+              uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const uint32_t ww[4] = {oo[r].x, oo[r].y, oo[r].z, oo[r].w};
-            uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
+              for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
+              for (int q = 0; q < TT; ++q)
 #pragma unroll
-            for (int q = 0; q < TT; ++q)
+                for (int j = 0; j < 3; ++j) {
+                  const uint32_t dd[4] = {dg[u][q][j].x, dg[u][q][j].y, dg[u][q][j].z, dg[u][q][j].w};
+                  int a = acc[r][q][j];
 #pragma unroll
-              for (int j = 0; j < 3; ++j) {
-                const uint32_t dd[4] = {dg[q][j].x, dg[q][j].y, dg[q][j].z, dg[q][j].w};
-                int a = acc[r][q][j];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
-                acc[r][q][j] = a;
-              }
+                  for (int k = 0; k < 4; ++k)
+                    a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
+                  acc[r][q][j] = a;
+                }
+            }
           }
         }
-      }
     };
     if constexpr (AHEAD == 1) {
       Words wa, wb;
@@ -417,11 +419,12 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
     // packed rows out (reset's founder gather, a cross without run-ahead): the pipelined stream; without
     // GEBV only where the host asks for it (p.seq > 1: long rows in turns)
     if (p.outp && (TT > 0 || p.seq > 1)) {
-      constexpr int V = TT == 0 ? kLongRowVectors : 1;
+      // with GEBV in the stream: two vectors per lane and trip when the observation is written too (-2.5 % at
+      // 16 x 256 x 10k), one otherwise
       if (p.outb)
-        packed_stream_role<TT, MODE, R, true, V>(p, (int)blockIdx.x, wave, &rwl);
+        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors>(p, (int)blockIdx.x, wave, &rwl);
       else
-        packed_stream_role<TT, MODE, R, false, V>(p, (int)blockIdx.x, wave, &rwl);
+        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : 1>(p, (int)blockIdx.x, wave, &rwl);
       return;
     }
   }
@@ -430,11 +433,21 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 
 // cross_kernel (row_kernels.h) with the packed row role: waves 0-3 stream generation g, waves 4-7
 // make the masks of generation g+1.
+// fp.out != null (MW = 4 only): the last fp.E workgroups of the grid draw the founders of the reset that follows
+// this step (founders_role): 12 us of LDS sorting by 16 workgroups that would otherwise be a launch of its own
+// between the horizon step and the founder gather.
 template <int TT, int MW, int R>
-__global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp) {
+__global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp,
+                                                          const FoundersParams fp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
+  if constexpr (MW == 4) {
+    if (fp.out && (int)blockIdx.x >= (int)gridDim.x - fp.E) {  // uniform per workgroup
+      founders_role(fp, (int)blockIdx.x - ((int)gridDim.x - fp.E), reinterpret_cast<uint64_t *>(lds_raw));
+      return;
+    }
+  }
   prime_next_reward(rp.reward_next, rp.n_envs);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if (MW == 4 || rp.reward) {  // uniform: the whole workgroup meets here or nowhere
@@ -455,11 +468,10 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 #if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
-          constexpr int V = TT == 0 ? kLongRowVectors : 1;
           if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true, V>(rp, (int)blockIdx.x, wave, &rwl);
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors>(rp, (int)blockIdx.x, wave, &rwl);
           else
-            packed_stream_role<TT, MODE_CROSS, R, false, V>(rp, (int)blockIdx.x, wave, &rwl);
+            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : 1>(rp, (int)blockIdx.x, wave, &rwl);
           return;
         }
       }
@@ -470,11 +482,12 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
   } else {
     if (mp.sites) {  // long rows: one gamete stream per lane, site words to memory (mask_stream.h)
-      mask_stream_role(mp, (int)blockIdx.x * 4 + wave - 4, (int)gridDim.x * 4);
+      mask_stream_role(mp, (int)blockIdx.x * 4 + wave - 4, ((int)gridDim.x - (fp.out ? fp.E : 0)) * 4);
       return;
     }
+    const int n_main = (int)gridDim.x - (fp.out ? fp.E : 0);  // without the workgroups that draw founders
     int iter = 0;  // crosses in turns when the grid is shorter than the mask work (cross_kernel)
-    for (int mb = (int)blockIdx.x; mb < mp.n_blocks; mb += (int)gridDim.x, ++iter)
+    for (int mb = (int)blockIdx.x; mb < mp.n_blocks; mb += n_main, ++iter)
       mask_role<4, SYNC_COUNTER>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
   }
 }

@@ -1011,10 +1011,10 @@ struct FoundersParams {
   int32_t E_total, env_offset;  // env e here is env env_offset + e of E_total (bh_set_env_window)
 };
 
-__global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
-  extern __shared__ __align__(16) uint64_t fk[];  // P keys, then 2 x P int32 orders
+// the draw of env e by one workgroup of any size; fk: 16 P bytes of LDS (P keys, then 2 x P int32 orders)
+__device__ __forceinline__ void founders_role(const FoundersParams &p, const int e, uint64_t *fk) {
   int32_t *x = reinterpret_cast<int32_t *>(fk + p.P), *y = x + p.P;
-  const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E_total + 1), (uint32_t)(1 + p.env_offset + e), p.layout);
   for (int i = tid; i < p.N; i += nt) x[i] = i;
   const int L = p.N + (p.N & 1), h = L >> 1;
@@ -1055,6 +1055,11 @@ __global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) 
     y = t;
   }
   for (int i = tid; i < p.n; i += nt) p.out[(int64_t)e * p.n + i] = x[i];
+}
+
+__global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
+  extern __shared__ __align__(16) uint64_t fk_lds[];
+  founders_role(p, (int)blockIdx.x, fk_lds);
 }
 
 }  // namespace bh

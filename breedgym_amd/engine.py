@@ -319,12 +319,13 @@ class HipEngine(EngineBase):
         _lib.check(self._L.bh_topk(self._h, s2.data_ptr(), s2.shape[0], s2.shape[1], int(k), out.data_ptr()))
         return out.reshape(*s.shape[:-1], int(k))
 
-    def founders(self, env_key: np.ndarray, n_envs: int, n_germplasm: int, n: int):
-        """Founder draw of ``VecBreedGym.reset`` on the device -> ((n_envs * n,) int32 tensor, new key)."""
+    def founders(self, env_key: np.ndarray, n_envs: int, n_germplasm: int, n: int, deferred: bool = False):
+        """Founder draw of ``VecBreedGym.reset`` on the device -> ((n_envs * n,) int32 tensor, new key).
+        ``deferred``: asked for ahead of a ``cross_packed`` call, whose launch then makes the draw as well."""
         k = np.ascontiguousarray(env_key, np.uint32).copy()
         out = torch.empty((int(n_envs) * int(n),), dtype=torch.int32, device=self.device)
         _lib.check(
-            self._L.bh_founders_device(
+            (self._L.bh_founders_deferred if deferred else self._L.bh_founders_device)(
                 self._h, k.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(n_envs), int(n_germplasm), int(n),
                 out.data_ptr(),
             )

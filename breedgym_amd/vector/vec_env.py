@@ -109,6 +109,7 @@ class VecBreedGym(_VectorEnvBase):
         self._prows = None  # storage="bits": (E * n, packed_pitch) bit-plane rows, the state between steps
         self._germ_prows = None
         self._n = None
+        self._founders_ahead = None  # (indices, key after the draw) made by the horizon step's launch for its reset
         self._rew_primed = None  # (E,) f32 the last cross launch left holding -inf: the next step's reward buffer
         self.step_idx = None
         self.reset_infos = {}
@@ -199,6 +200,11 @@ class VecBreedGym(_VectorEnvBase):
         # ... and this launch primes the buffer of the next step that has a reward
         next_idx = 0 if (done and self.autoreset) else self.step_idx + 1
         rew_next = eng.empty((E,), torch.float32) if (self.reward_shaping or next_idx + 1 == self.num_generations) else None
+        if done and self.autoreset and self.storage == "bits":
+            # the reset that follows needs its founders: their draw depends on the env key only and rides on this
+            # step's launch instead of being a launch of its own (bh_founders_deferred)
+            self._founders_ahead = eng.founders(self.random_key, E, len(self.germplasm), self.individual_per_gen,
+                                                deferred=True)
         if self.storage == "bits":
             outp = eng.empty_packed(E * n_out)
             # at the horizon the observation handed out is the next episode's first one (vec_env.py:102-107):
@@ -244,7 +250,11 @@ class VecBreedGym(_VectorEnvBase):
 
         eng = self.simulator.engine
         E, n = self.num_envs, self.individual_per_gen
-        idx, self.random_key = eng.founders(self.random_key, E, len(self.germplasm), n)
+        ahead, self._founders_ahead = self._founders_ahead, None
+        if ahead is not None and seed is None and ahead[0].numel() == E * n:
+            idx, self.random_key = ahead  # drawn by the horizon step's launch from this same key
+        else:
+            idx, self.random_key = eng.founders(self.random_key, E, len(self.germplasm), n)
         gebv = eng.empty((E, n, eng.n_traits), torch.float32)
         if self.storage == "bits":
             if self._germ_prows is None:

@@ -223,6 +223,13 @@ int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_
 int bh_founders_device(bh_ctx *ctx, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm,
                        int64_t n, int32_t *d_out);
 
+/* bh_founders_device, asked for AHEAD of a bh_cross_packed call: env_key is advanced now, the indices are written
+ * by the next two-role launch of the context (its grid grows by n_envs workgroups; for n_germplasm <= 1024) or,
+ * failing that, by a launch of their own before anything else of this context runs.  VecBreedGym's horizon step
+ * uses it: the reset's founder draw costs no launch of its own between the step and the founder gather. */
+int bh_founders_deferred(bh_ctx *ctx, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm,
+                         int64_t n, int32_t *d_out);
+
 #ifdef __cplusplus
 }
 #endif

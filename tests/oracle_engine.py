@@ -166,7 +166,7 @@ class OracleEngine(EngineBase):
         out = np.stack([co.topk(row, k) for row in s2])
         return torch.from_numpy(out.reshape(*s.shape[:-1], k))
 
-    def founders(self, env_key, n_envs, n_germplasm, n):
+    def founders(self, env_key, n_envs, n_germplasm, n, deferred=False):
         co.set_threefry_layout(self.threefry_layout)
         off, total = self.env_window
         if total:  # the draw of the whole, this shard's envs kept
