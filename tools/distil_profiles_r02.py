@@ -57,7 +57,7 @@ pmc = {f"{kind}_{cfg}": counters(f"{kind}_{cfg}") for cfg in ("c2", "c3", "c5") 
 kernels = []
 for cfg in ("c2", "c3", "c5"):
     for k, d in pmc[f"fetch_{cfg}"].items():
-        if not any(t in k for t in ("packed_cross_kernel", "gebv_bits_kernel", "gebv_finish_kernel", "gebv_mfma_kernel")):
+        if not any(t in k for t in ("packed_cross_kernel", "packed_long_kernel", "mask_finish_kernel", "gebv_bits_kernel", "gebv_finish_kernel", "gebv_mfma_kernel")):
             continue
         fk = d.get("FETCH_SIZE", 0.0)
         wk = pmc[f"write_{cfg}"].get(k, {}).get("WRITE_SIZE", 0.0)
