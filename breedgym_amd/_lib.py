@@ -93,7 +93,7 @@ SIGNATURES = {
     "bh_memcpy_d2h": (_int, [_vp, _vp, _vp, _i64]),
     "bh_upload_population": (_int, [_vp, _vp, _i64, _vp, _int]),
     "bh_download_population": (_int, [_vp, _vp, _i64, _vp]),
-    "bh_cross": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp]),
+    "bh_cross": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp, _i64]),
     "bh_set_mask_prefetch": (_int, [_vp, _int]),
     "bh_gather": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "bh_gebv": (_int, [_vp, _vp, _i64, _vp]),
@@ -103,7 +103,7 @@ SIGNATURES = {
     "bh_optimal_haploid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "bh_packed_pitch": (_i64, [_vp]),
     "bh_pack": (_int, [_vp, _vp, _i64, _vp]),
-    "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp, _vp]),
+    "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp, _vp, _i64]),
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
     "bh_set_threefry_layout": (_int, [_vp, _int]),

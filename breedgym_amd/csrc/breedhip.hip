@@ -948,10 +948,11 @@ int bh_download_population(bh_ctx *c, const uint8_t *d_src, int64_t rows, uint8_
 static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_pool, int64_t n_envs,
                       int64_t pool_rows, const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
                       uint8_t *d_out_bytes, uint16_t *d_out_packed, float *d_gebv, float *d_reward,
-                      float *d_reward_next) {
+                      float *d_reward_next, int64_t reward_pitch) {
   if (int rc = check_ctx(c)) return rc;
   if (!sim_key) return fail(BH_ERR_BAD_ARG, "%s: null sim_key", who);
   if (n_envs < 0 || n_out < 0 || pool_rows < 0) return fail(BH_ERR_BAD_ARG, "%s: negative size", who);
+  if ((d_reward || d_reward_next) && reward_pitch < 1) return fail(BH_ERR_BAD_ARG, "%s: reward_pitch must be >= 1", who);
   if (rng_mode < 0 || rng_mode > (BH_RNG_INDEPENDENT | BH_RNG_DOUBLE_HAPLOID))
     return fail(BH_ERR_BAD_ARG, "%s: unknown rng_mode %d", who, rng_mode);
   const bool dh = (rng_mode & BH_RNG_DOUBLE_HAPLOID) != 0;
@@ -1029,8 +1030,10 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // with an atomic max into a buffer that holds -inf -- left so by the launch before (d_reward_next of that
     // call), or set so now
     const bool reward_in_launch = d_reward && fused;
-    if (reward_in_launch && !(c->primed_reward == d_reward && c->primed_envs == n_envs))
-      BH_HIP(hipMemsetD32Async(d_reward, (int)0xFF800000u, (size_t)n_envs, c->stream));
+    if (reward_in_launch && !(c->primed_reward == d_reward && c->primed_envs == n_envs)) {
+      hipLaunchKernelGGL(bh::prime_reward_kernel, dim3(1), dim3(256), 0, c->stream, d_reward, (int)n_envs, reward_pitch);
+      BH_HIP(hipGetLastError());
+    }
     int rc;
     if (packed) {
       bh::PackedParams p = packed_params(c);
@@ -1047,6 +1050,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.tcount = tcount;
       p.reward = reward_in_launch ? d_reward : nullptr;
       p.reward_next = d_reward_next;
+      p.reward_pitch = reward_pitch;
       p.n_envs = (int32_t)n_envs;
       const int turns = (tcount == 0 && (!run_ahead || mw == 4)) ? long_row_turns(c, rows) : 0;
       p.seq = turns;
@@ -1087,6 +1091,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.tcount = tcount;
       p.reward = reward_in_launch ? d_reward : nullptr;
       p.reward_next = d_reward_next;
+      p.reward_pitch = reward_pitch;
       p.n_envs = (int32_t)n_envs;
       if (run_ahead) {
         if (mw == 1)
@@ -1120,12 +1125,16 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       if (rc) return rc;
     }
     // the reward of vec_env.py:97 where the GEBV came from a pass of its own: a reduction kernel behind it
-    if (d_reward && !reward_in_launch)
-      if (int rc2 = bh_reward_max(c, d_gebv, n_envs, n_out * c->T, d_reward)) return rc2;
+    if (d_reward && !reward_in_launch) {
+      hipLaunchKernelGGL(bh::reward_max_kernel, dim3((unsigned)n_envs), dim3(256), 0, c->stream, d_gebv, n_out * c->T,
+                         d_reward, reward_pitch);
+      BH_HIP(hipGetLastError());
+    }
     c->primed_reward = d_reward_next;
     c->primed_envs = d_reward_next ? n_envs : 0;
   } else if (d_reward_next && n_envs > 0) {
-    BH_HIP(hipMemsetD32Async(d_reward_next, (int)0xFF800000u, (size_t)n_envs, c->stream));
+    hipLaunchKernelGGL(bh::prime_reward_kernel, dim3(1), dim3(256), 0, c->stream, d_reward_next, (int)n_envs, reward_pitch);
+    BH_HIP(hipGetLastError());
     c->primed_reward = d_reward_next;
     c->primed_envs = n_envs;
   }
@@ -1136,16 +1145,16 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
 
 int bh_cross(bh_ctx *c, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
              int64_t n_out, uint32_t sim_key[2], int rng_mode, uint8_t *d_out, float *d_gebv, float *d_reward,
-             float *d_reward_next) {
+             float *d_reward_next, int64_t reward_pitch) {
   return cross_impl(c, "bh_cross", false, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode, d_out, nullptr,
-                    d_gebv, d_reward, d_reward_next);
+                    d_gebv, d_reward, d_reward_next, reward_pitch);
 }
 
 int bh_cross_packed(bh_ctx *c, const uint16_t *d_pool, int64_t n_envs, int64_t pool_rows, const int32_t *d_idx,
                     int64_t n_out, uint32_t sim_key[2], int rng_mode, uint16_t *d_out_packed, uint8_t *d_out_bytes,
-                    float *d_gebv, float *d_reward, float *d_reward_next) {
+                    float *d_gebv, float *d_reward, float *d_reward_next, int64_t reward_pitch) {
   return cross_impl(c, "bh_cross_packed", true, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode,
-                    d_out_bytes, d_out_packed, d_gebv, d_reward, d_reward_next);
+                    d_out_bytes, d_out_packed, d_gebv, d_reward, d_reward_next, reward_pitch);
 }
 
 int64_t bh_packed_pitch(const bh_ctx *c) { return c ? (int64_t)16 * c->nw : 0; }
@@ -1297,7 +1306,7 @@ int bh_reward_max(bh_ctx *c, const float *d_gebv, int64_t n_envs, int64_t per_en
   if (n_envs == 0) return BH_OK;
   if (!d_gebv || !d_reward) return fail(BH_ERR_BAD_ARG, "bh_reward_max: null device pointer");
   hipLaunchKernelGGL(bh::reward_max_kernel, dim3((unsigned)n_envs), dim3(256), 0, c->stream, d_gebv, per_env,
-                     d_reward);
+                     d_reward, (int64_t)1);
   BH_HIP(hipGetLastError());
   return BH_OK;
 }

@@ -54,6 +54,7 @@ struct PackedParams {
   int32_t seq;  // row groups a wave of packed_stream_role streams one after the other (>= 1)
   float *reward;       // cross: (n_envs) max GEBV per env, holding -inf on entry (reward_note), or null
   float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
+  int64_t reward_pitch;  // floats between the words of two envs in both (RowParams)
   int32_t n_envs;
 };
 
@@ -194,10 +195,10 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
               best = g != g ? best : fmaxf(best, g);
             }
           if constexpr (MODE == MODE_CROSS)
-            if (p.reward) reward_row(rw, p.reward, env0, c0 + r, p.n_out, best);
+            if (p.reward) reward_row(rw, p.reward, p.reward_pitch, env0, c0 + r, p.n_out, best);
         }
       if constexpr (MODE == MODE_CROSS)
-        if (p.reward) reward_wave_done(rw, p.reward, env0, expected);
+        if (p.reward) reward_wave_done(rw, p.reward, p.reward_pitch, env0, expected);
     }
   }
 }
@@ -397,11 +398,11 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
             const float g = (float)((double)sum * p.scale[p.t0 + t]);
             p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
             if constexpr (MODE == MODE_CROSS)
-              if (p.reward) reward_row(rw, p.reward, env0, c0 + r, p.n_out, g);
+              if (p.reward) reward_row(rw, p.reward, p.reward_pitch, env0, c0 + r, p.n_out, g);
           }
         }
       if constexpr (MODE == MODE_CROSS)
-        if (lane == 0 && p.reward) reward_wave_done(rw, p.reward, env0, expected);
+        if (lane == 0 && p.reward) reward_wave_done(rw, p.reward, p.reward_pitch, env0, expected);
     }
   }
 }
@@ -409,7 +410,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   __shared__ RewardLds rwl;
-  prime_next_reward(p.reward_next, p.n_envs);
+  prime_next_reward(p.reward_next, p.n_envs, p.reward_pitch);
   if (p.reward) {
     if (threadIdx.x == 0) reward_lds_init(&rwl);
     __syncthreads();
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
       return;
     }
   }
-  prime_next_reward(rp.reward_next, rp.n_envs);
+  prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if (MW == 4 || rp.reward) {  // uniform: the whole workgroup meets here or nowhere
     if (threadIdx.x == 0) {
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 // rows / (4 R seq) are few enough to be resident all at once (no tail of late workgroups doing mask work alone).
 template <int R, int MASK_WAVES>
 __global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(const PackedParams rp, const MaskParams mp) {
-  prime_next_reward(rp.reward_next, rp.n_envs);
+  prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only
   if (wave < 4) return;

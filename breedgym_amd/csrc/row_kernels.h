@@ -84,8 +84,16 @@ struct RowParams {
   int32_t rng_shared;     // 1: mask row = env-local cross index (all envs share the masks)
   float *reward;          // cross: (n_envs) max GEBV per env, holding -inf on entry (reward_note), or null
   float *reward_next;     // (n_envs) set to -inf by this launch for a later one, or null
+  int64_t reward_pitch;   // floats from one env's word to the next in both (64: a cache line of its own per env --
+                          // the atomics of different envs then do not queue behind each other: +0.9 us instead of
+                          // +2.6 us on the 16 x 256 x 10k launch)
   int32_t n_envs;
 };
+
+// a reward buffer that was not left primed by a previous launch
+__global__ void prime_reward_kernel(float *reward, int n_envs, int64_t pitch) {
+  for (int64_t i = threadIdx.x; i < n_envs; i += blockDim.x) reward[i * pitch] = -INFINITY;
+}
 
 // reward[env] = max(reward[env], v) for a buffer that held -inf before the launch: the sign decides between
 // a signed max and an unsigned min on the same bits (non-negative floats order like ints, negative ones in
@@ -121,22 +129,23 @@ __device__ __forceinline__ void reward_lds_init(RewardLds *rw) {  // thread 0, b
   rw->best[1] = 0;
 }
 // one lane per wave: `row`'s value
-__device__ __forceinline__ void reward_row(RewardLds *rw, float *reward, int env0, int row, int n_out, float v) {
+__device__ __forceinline__ void reward_row(RewardLds *rw, float *reward, int64_t pitch, int env0, int row, int n_out,
+                                           float v) {
   if (v != v) return;
   const int env = row / n_out;
   if (rw && env - env0 < 2)
     atomicMax(&rw->best[env - env0], reward_key(v));
   else
-    reward_note(reward, env, v);
+    reward_note(reward + (int64_t)env * pitch, 0, v);
 }
 // one lane per wave, after its reward_row calls; `expected` = row waves of this workgroup that have rows
-__device__ __forceinline__ void reward_wave_done(RewardLds *rw, float *reward, int env0, int expected) {
+__device__ __forceinline__ void reward_wave_done(RewardLds *rw, float *reward, int64_t pitch, int env0, int expected) {
   if (!rw) return;
   if (atomicAdd(&rw->count, 1u) + 1u == (unsigned)expected) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const unsigned k = atomicMax(&rw->best[s], 0u);
-      if (k) reward_note(reward, env0 + s, reward_unkey(k));
+      if (k) reward_note(reward + (int64_t)(env0 + s) * pitch, 0, reward_unkey(k));
     }
   }
 }
@@ -151,9 +160,9 @@ __device__ __forceinline__ void reward_wg_layout(int block, int n_blocks, int pe
 }
 
 // what the first workgroup of every launch does for the launch after it
-__device__ __forceinline__ void prime_next_reward(float *reward_next, int n_envs) {
+__device__ __forceinline__ void prime_next_reward(float *reward_next, int n_envs, int64_t pitch) {
   if (reward_next && blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n_envs; i += blockDim.x) reward_next[i] = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n_envs; i += blockDim.x) reward_next[i * pitch] = -INFINITY;
 }
 
 // Blocks b, b+8, b+16.. are dealt to the same XCD (round-robin dispatch).  Hand every XCD a
@@ -708,10 +717,10 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
               best = g != g ? best : fmaxf(best, g);
             }
           if constexpr (MODE == MODE_CROSS)
-            if (p.reward) reward_row(WAVES == 1 ? rw : nullptr, p.reward, env0, c0 + r, p.n_out, best);
+            if (p.reward) reward_row(WAVES == 1 ? rw : nullptr, p.reward, p.reward_pitch, env0, c0 + r, p.n_out, best);
         }
       if constexpr (MODE == MODE_CROSS)
-        if (p.reward && WAVES == 1) reward_wave_done(rw, p.reward, env0, expected);
+        if (p.reward && WAVES == 1) reward_wave_done(rw, p.reward, p.reward_pitch, env0, expected);
     }
   }
 }
@@ -851,10 +860,10 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
       if (lane == 0 && live[r]) {
         const float g = (float)((double)s * p.scale[p.t0 + t]);
         p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
-        if (p.reward) reward_row(rw, p.reward, env0, c0 + r, p.n_out, g);
+        if (p.reward) reward_row(rw, p.reward, p.reward_pitch, env0, c0 + r, p.n_out, g);
       }
     }
-  if (lane == 0 && p.reward) reward_wave_done(rw, p.reward, env0, expected);
+  if (lane == 0 && p.reward) reward_wave_done(rw, p.reward, p.reward_pitch, env0, expected);
 }
 
 template <int WAVES>
@@ -867,7 +876,7 @@ template <int WAVES, int TT, int MODE, int R, bool LONG>
 __global__ __launch_bounds__(256) void row_kernel(const RowParams p) {
   __shared__ double red[4 * (TT > 0 ? TT : 1)];
   __shared__ RewardLds rwl;
-  prime_next_reward(p.reward_next, p.n_envs);
+  prime_next_reward(p.reward_next, p.n_envs, p.reward_pitch);
   if (p.reward) {
     if (threadIdx.x == 0) reward_lds_init(&rwl);
     __syncthreads();
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
-  prime_next_reward(rp.reward_next, rp.n_envs);
+  prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if (MW == 4 || rp.reward) {  // uniform: the whole workgroup meets here or nowhere
     if (threadIdx.x == 0) {
@@ -927,7 +936,7 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
 }
 
 // reward[e] = max over the env's (individuals x traits) GEBV block (vec_env.py:97)
-__global__ __launch_bounds__(256) void reward_max_kernel(const float *g, int64_t per_env, float *out) {
+__global__ __launch_bounds__(256) void reward_max_kernel(const float *g, int64_t per_env, float *out, int64_t pitch) {
   __shared__ float part[4];
   const int e = blockIdx.x, tid = threadIdx.x;
   const float *ge = g + (int64_t)e * per_env;
@@ -937,7 +946,7 @@ __global__ __launch_bounds__(256) void reward_max_kernel(const float *g, int64_t
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if ((tid & 63) == 0) part[tid >> 6] = m;
   __syncthreads();
-  if (tid == 0) out[e] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+  if (tid == 0) out[e * pitch] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
 
 // ---- top-k by bitonic sort in LDS --------------------------------------------------------

@@ -95,6 +95,15 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _reward_pitch(reward, reward_next) -> int:
+    """Floats between two envs' words in the reward buffers of a cross call (both must agree)."""
+    pitches = {int(t.stride(0)) if t.numel() > 1 else None for t in (reward, reward_next) if t is not None}
+    pitches.discard(None)
+    if len(pitches) > 1:
+        raise ValueError("reward and reward_next must have the same stride")
+    return pitches.pop() if pitches else 1
+
+
 class EngineBase:
     """Row layout and memory helpers shared by every engine; operators are abstract.
 
@@ -106,6 +115,11 @@ class EngineBase:
 
     def empty(self, shape, dtype) -> torch.Tensor:
         return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def empty_reward(self, n_envs: int) -> torch.Tensor:
+        """(n_envs,) f32 reward buffer, every env's word on a cache line of its own (the atomic maxima of a launch
+        then do not queue behind each other): a strided view."""
+        return torch.empty_strided((int(n_envs),), (64,), dtype=torch.float32, device=self.device)
 
     def empty_packed(self, rows: int) -> torch.Tensor:
         """Bit-plane rows: ``packed_pitch = 16 * ceil(M / 64)`` bytes each (include/breedhip.h)."""
@@ -198,6 +212,7 @@ class HipEngine(EngineBase):
         self.packed_pitch = int(L.bh_packed_pitch(h))
         self.threefry_layout = "original"
         self.set_threefry_layout(threefry_layout)
+        self._key_obj, self._key_ptr = None, None
         # torch's default stream is the null stream, which is also the context's default
 
     def close(self):
@@ -236,7 +251,7 @@ class HipEngine(EngineBase):
             self._L.bh_cross(
                 self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
                 key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out.data_ptr(), _ptr(gebv),
-                _ptr(reward), _ptr(reward_next),
+                _ptr(reward), _ptr(reward_next), _reward_pitch(reward, reward_next),
             )
         )
 
@@ -273,9 +288,32 @@ class HipEngine(EngineBase):
             self._L.bh_cross_packed(
                 self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out,
                 key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(rng_mode), out_packed.data_ptr(),
-                _ptr(out_bytes), _ptr(gebv), _ptr(reward), _ptr(reward_next),
+                _ptr(out_bytes), _ptr(gebv), _ptr(reward), _ptr(reward_next), _reward_pitch(reward, reward_next),
             )
         )
+
+    def cross_step(self, pool, n_envs, pool_rows, idx, n_out, key, rng_mode, want_obs, reward, want_next):
+        """``VecBreedGym.step``'s call, thin: allocates this generation's blocks and makes the one C call
+        (bh_cross_packed), nothing else -- at 16 x 256 x 10k the launch takes 23 us and the host path must stay
+        below it.  ``idx`` must be an int32 device tensor (E, n_out, 2), ``key`` a C-contiguous uint32[2] array
+        (advanced in place), ``reward`` None or a buffer from an earlier call's ``want_next``.
+        -> (packed rows, byte rows or None, gebv (E, n_out, T), the next step's primed reward buffer or None)"""
+        dev, rows = self.device, n_envs * n_out
+        outp = torch.empty((rows, self.packed_pitch), dtype=torch.uint8, device=dev)
+        out = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev) if want_obs else None
+        gebv = torch.empty((n_envs, n_out, self.n_traits), dtype=torch.float32, device=dev)
+        nxt = torch.empty_strided((n_envs,), (64,), dtype=torch.float32, device=dev) if want_next else None
+        if key is not self._key_obj:  # the simulator keeps one key array: its address is looked up once
+            assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
+            self._key_obj, self._key_ptr = key, key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        rc = self._L.bh_cross_packed(
+            self._h, pool.data_ptr(), n_envs, pool_rows, idx.data_ptr(), n_out, self._key_ptr, rng_mode,
+            outp.data_ptr(), None if out is None else out.data_ptr(), gebv.data_ptr(),
+            None if reward is None else reward.data_ptr(), None if nxt is None else nxt.data_ptr(), 64,
+        )
+        if rc:
+            _lib.check(rc)
+        return outp, out, gebv, nxt
 
     def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None) -> None:
         """Rows ``idx`` (or 0..n_rows-1) of packed ``src`` -> packed and/or byte-layout rows and/or GEBV."""

@@ -109,6 +109,8 @@ class VecBreedGym(_VectorEnvBase):
         self._prows = None  # storage="bits": (E * n, packed_pitch) bit-plane rows, the state between steps
         self._germ_prows = None
         self._n = None
+        self._fast_step = hasattr(self.simulator.engine, "cross_step")  # the thin call of the HIP engine
+        self._all_false, self._all_true = np.full(self.num_envs, False), np.full(self.num_envs, True)
         self._founders_ahead = None  # (indices, key after the draw) made by the horizon step's launch for its reset
         self._rew_primed = None  # (E,) f32 the last cross launch left holding -inf: the next step's reward buffer
         self.step_idx = None
@@ -185,10 +187,15 @@ class VecBreedGym(_VectorEnvBase):
     def step(self, actions) -> Tuple[DeviceArray, np.ndarray, np.ndarray, np.ndarray, dict]:
         if self._n is None:
             raise RuntimeError("call reset() before step()")
-        eng = self.simulator.engine
-        idx = self._device_actions(actions)
+        sim = self.simulator
+        eng = sim.engine
+        if type(actions) is torch.Tensor and actions.dtype == torch.int32 and actions.device == eng.device \
+                and actions.dim() == 3 and actions.shape[0] == self.num_envs and actions.shape[2] == 2 \
+                and actions.is_contiguous():
+            idx = actions  # already what the kernel reads
+        else:
+            idx = self._device_actions(actions)
         E, n_pool, n_out = self.num_envs, self._n, idx.shape[1]
-        gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
         done = self.step_idx + 1 == self.num_generations
         # the reward (max GEBV per env, vec_env.py:96-98) comes out of the same launch when it is due: the row
         # waves note their GEBV with atomic maxima into a buffer the launch before left holding -inf
@@ -196,44 +203,55 @@ class VecBreedGym(_VectorEnvBase):
         if self.reward_shaping or done:
             rew_dev, self._rew_primed = self._rew_primed, None
             if rew_dev is None or rew_dev.shape[0] != E:
-                rew_dev = eng.empty((E,), torch.float32)  # not primed: the library fills it first
+                rew_dev = eng.empty_reward(E)  # not primed: the library fills it first
         # ... and this launch primes the buffer of the next step that has a reward
         next_idx = 0 if (done and self.autoreset) else self.step_idx + 1
-        rew_next = eng.empty((E,), torch.float32) if (self.reward_shaping or next_idx + 1 == self.num_generations) else None
-        if done and self.autoreset and self.storage == "bits":
-            # the reset that follows needs its founders: their draw depends on the env key only and rides on this
-            # step's launch instead of being a launch of its own (bh_founders_deferred)
-            self._founders_ahead = eng.founders(self.random_key, E, len(self.germplasm), self.individual_per_gen,
-                                                deferred=True)
+        want_next = self.reward_shaping or next_idx + 1 == self.num_generations
         if self.storage == "bits":
-            outp = eng.empty_packed(E * n_out)
+            if done and self.autoreset:
+                # the reset that follows needs its founders: their draw depends on the env key only and rides on
+                # this step's launch instead of being a launch of its own (bh_founders_deferred)
+                self._founders_ahead = eng.founders(self.random_key, E, len(self.germplasm), self.individual_per_gen,
+                                                    deferred=True)
             # at the horizon the observation handed out is the next episode's first one (vec_env.py:102-107):
             # this generation's byte layout would be written for nobody
             want_obs = self.observations == "eager" and not (done and self.autoreset)
-            out = eng.empty_population(E * n_out) if want_obs else None
-            self.simulator.cross_indexed_packed(self._prows, E, n_pool, idx, n_out, outp, out, gebv, self._rng_mode,
-                                                rew_dev, rew_next)
+            if self._fast_step:
+                key = sim.random_key
+                if key.dtype != np.uint32 or not key.flags.c_contiguous:
+                    key = sim.random_key = np.ascontiguousarray(key, np.uint32)
+                outp, out, gebv, rew_next = eng.cross_step(self._prows, E, n_pool, idx, n_out, key, self._rng_mode,
+                                                           want_obs, rew_dev, want_next)
+            else:
+                gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
+                rew_next = eng.empty_reward(E) if want_next else None
+                outp = eng.empty_packed(E * n_out)
+                out = eng.empty_population(E * n_out) if want_obs else None
+                sim.cross_indexed_packed(self._prows, E, n_pool, idx, n_out, outp, out, gebv, self._rng_mode, rew_dev,
+                                         rew_next)
             self._adopt(out, n_out, outp)
         else:
+            gebv = eng.empty((E, n_out, eng.n_traits), torch.float32)
+            rew_next = eng.empty_reward(E) if want_next else None
             out = eng.empty_population(E * n_out)
-            self.simulator.cross_indexed(self._brows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev, rew_next)
+            sim.cross_indexed(self._brows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev, rew_next)
             self._adopt(out, n_out)
         self._rew_primed = rew_next
         self.step_idx += 1
 
-        infos = {"GEBV": DeviceArray.wrap(gebv)}
+        infos = {"GEBV": gebv.as_subclass(DeviceArray)}
         if rew_dev is None:
             rews = np.zeros(self.num_envs)
         elif self.sync_rewards:
             rews = rew_dev.cpu().numpy()  # the reference's np.max(...) also syncs here (vec_env.py:97-98)
         else:
-            rews = DeviceArray.wrap(rew_dev)
+            rews = rew_dev.as_subclass(DeviceArray)
 
         if done and self.autoreset:
             self.reset()  # like the reference: obs is post-reset, infos pre-reset (vec_env.py:102-107)
 
-        terminated = np.full(self.num_envs, False)
-        truncated = np.full(self.num_envs, done)
+        terminated = self._all_false.copy()
+        truncated = self._all_true.copy() if done else self._all_false.copy()
         return self._observation(), rews, terminated, truncated, infos
 
     def reset(self, seed: Optional[int] = None, options: Optional[dict] = None) -> Tuple[DeviceArray, dict]:

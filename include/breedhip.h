@@ -115,12 +115,15 @@ int bh_download_population(bh_ctx *ctx, const uint8_t *d_src, int64_t rows, uint
  *                                           library fills it first; elsewhere a reduction kernel follows
  *   d_reward_next (n_envs) f32 or NULL      left holding -inf by this launch, for the caller to pass as
  *                                           d_reward of its next call (saves that fill)
+ *   reward_pitch                            floats from one env's word to the next in d_reward and
+ *                                           d_reward_next (>= 1; 64 gives every env a cache line of its own,
+ *                                           so that the atomics of different envs do not queue behind each other)
  *   sim_key host, in/out                    the simulator's threefry key; advanced once
  *                                           per call like `Simulator.cross` does
  * d_out must not alias d_pool. */
 int bh_cross(bh_ctx *ctx, const uint8_t *d_pool, int64_t n_envs, int64_t pool_rows,
              const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
-             uint8_t *d_out, float *d_gebv, float *d_reward, float *d_reward_next);
+             uint8_t *d_out, float *d_gebv, float *d_reward, float *d_reward_next, int64_t reward_pitch);
 
 /* Run-ahead of the crossover masks.  The masks of a generation depend on the key chain and
  * the batch size only, never on the parents, so every bh_cross launch also makes the masks of
@@ -176,7 +179,7 @@ int bh_pack(bh_ctx *ctx, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_pack
 int bh_cross_packed(bh_ctx *ctx, const uint16_t *d_pool, int64_t n_envs, int64_t pool_rows,
                     const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
                     uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv, float *d_reward,
-                    float *d_reward_next);
+                    float *d_reward_next, int64_t reward_pitch);
 /* bh_gather on packed rows (vec_env.py:126-129).  d_idx NULL = rows 0..n_rows-1 in order, which
  * makes this the unpack (d_out_bytes only) and the GEBV of packed rows (d_gebv only).  Any of
  * d_out_packed, d_out_bytes, d_gebv may be NULL. */

@@ -24,10 +24,10 @@ int main(int argc, char **argv) {
   bh_memcpy_h2d(ctx, pool, h.data(), h.size()); bh_memcpy_h2d(ctx, idx, hi.data(), hi.size() * 4); bh_sync(ctx);
   uint32_t key[2] = {0, 7};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) bh_cross(ctx, pool, E, n, idx, n, key, mode, out, gebv, nullptr, nullptr);
+  for (int i = 0; i < 5; ++i) bh_cross(ctx, pool, E, n, idx, n, key, mode, out, gebv, nullptr, nullptr, 1);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int i = 0; i < reps; ++i) bh_cross(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, gebv, nullptr, nullptr);
+  for (int i = 0; i < reps; ++i) bh_cross(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, gebv, nullptr, nullptr, 1);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("byte layout mode=%d M=%lld C=%lld : %.1f us per launch, %.1f M crosses/s, %.0f GB/s algorithmic\n", mode, (long long)M, (long long)rows,

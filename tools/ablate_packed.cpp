@@ -10,6 +10,7 @@
 int main(int argc, char **argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0, obs = argc > 2 ? atoi(argv[2]) : 1, wg = argc > 3 ? atoi(argv[3]) : 1;
   const int64_t M = argc > 4 ? atoll(argv[4]) : 10000, E = argc > 5 ? atoll(argv[5]) : 16, n = argc > 6 ? atoll(argv[6]) : 256;
+  const int rew = argc > 7 ? atoi(argv[7]) : 0;  // 1: with the per-env reward noted in the launch
   const int reps = 50;
   std::vector<float> r(M, 0.0015f), eff(M, 1.0f);
   for (int64_t m = 0; m < M; m += M / 10) r[m] = 0.5f;
@@ -26,13 +27,15 @@ int main(int argc, char **argv) {
   std::vector<int32_t> hi(rows * 2); for (auto &v : hi) v = rand() % n;
   bh_memcpy_h2d(ctx, bytes, h.data(), h.size()); bh_memcpy_h2d(ctx, idx, hi.data(), hi.size() * 4);
   bh_pack(ctx, bytes, rows, pool); bh_sync(ctx);
+  float *rw[2] = {nullptr, nullptr};
+  if (rew) { bh_alloc(ctx, E * 64 * 4, (void **)&rw[0]); bh_alloc(ctx, E * 64 * 4, (void **)&rw[1]); }
   uint32_t key[2] = {0, 7};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; ++i) bh_cross_packed(ctx, pool, E, n, idx, n, key, mode, out, obs ? ob : nullptr, wg ? gebv : nullptr, nullptr, nullptr);
+  for (int i = 0; i < 5; ++i) bh_cross_packed(ctx, pool, E, n, idx, n, key, mode, out, obs ? ob : nullptr, wg ? gebv : nullptr, rw[i & 1], rw[1 - (i & 1)], rew ? 64 : 1);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
   for (int i = 0; i < reps; ++i)
-    bh_cross_packed(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, obs ? ob : nullptr, wg ? gebv : nullptr, nullptr, nullptr);
+    bh_cross_packed(ctx, i & 1 ? out : pool, E, n, idx, n, key, mode, i & 1 ? pool : out, obs ? ob : nullptr, wg ? gebv : nullptr, rw[(i + 1) & 1], rw[i & 1], rew ? 64 : 1);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("mode=%d obs=%d gebv=%d M=%lld C=%lld : %.1f us per launch\n", mode, obs, wg, (long long)M, (long long)rows, ms / reps * 1e3);
