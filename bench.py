@@ -59,7 +59,7 @@ def cross_bytes(M, C, B, storage, observations):
     return C * 6 * M + masks
 
 
-def cpu_baseline(gm, geno, rng_mode, seconds_hint=8.0):
+def cpu_baseline(gm, geno, rng_mode, seconds_hint=12.0):
     """The CPU oracle (a from-scratch port: the reference's chromax/JAX CPU path cannot be
     installed here or on the GPU box) timed on this host on a bounded sample of the same
     workload: whole 4096-cross generations of 370x10k (cross + GEBV + reward), OpenMP over
@@ -83,7 +83,7 @@ def cpu_baseline(gm, geno, rng_mode, seconds_hint=8.0):
     t0 = time.perf_counter()
     one_generation()  # also the warm-up
     first = time.perf_counter() - t0
-    reps = int(max(1, min(50, seconds_hint / max(first, 1e-3))))
+    reps = int(max(1, min(2000, seconds_hint / max(first, 1e-3))))  # ~12 s of 16-thread CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
         one_generation()
@@ -222,6 +222,8 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
                                      "per lane -- 2048 keyed crosses x 100k markers of Threefry; then site words -> masks)",
                                      nbytes + 2 * 4 * n * (M // 128 + 2) * 8, kms,  # + site words written and read back
                                      api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
+             "traffic": committed_traffic("packed_long_kernel")[0] if obs == "eager" else None,
+             "traffic_source": committed_traffic("packed_long_kernel")[1] if obs == "eager" else None,
              "gebv_pass_ms": kms_all - kms,
              "gebv_pass_note": "gebv_bits_kernel + gebv_finish_kernel over the bit-plane offspring (0.2 GB)",
              "step_frac_of_hbm_peak": (nbytes + E * n * packed_pitch(M)) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
@@ -255,7 +257,13 @@ def bench_c5(reps):
         "byte_rows": {"ms": ms_bytes, "individuals_per_s": N / (ms_bytes * 1e-3),
                       "roofline": roofline_of("gebv (bh_gebv, byte-layout rows)", N * 2 * M + eff_bytes, ms_bytes)},
         "bit_planes": {"ms": ms_bits, "individuals_per_s": N / (ms_bits * 1e-3),
-                       "roofline": roofline_of("gebv (bh_gather_packed, bit-plane rows)", N * packed_pitch(M) + eff_bytes, ms_bits),
+                       "roofline": roofline_of("gebv_bits_kernel<2,1> + gebv_finish_kernel (bh_gather_packed, bit-plane rows)",
+                                               N * packed_pitch(M) + eff_bytes, ms_bits,
+                                               traffic=committed_traffic("gebv_bits_kernel<2")[0],
+                                               traffic_source=committed_traffic("gebv_bits_kernel<2")[1],
+                                               note="51 MB of rows: not bound by its bytes any more but by the int8 MFMAs and "
+                                                    "their operand build",
+                                               mfma_int8_Tops=2.0 * N * M * 64 / (ms_bits * 1e-3) / 1e12, mfma_int8_peak_Tops=5000.0),
                        "api_level_GBps": N * 2 * M / (ms_bits * 1e-3) / 1e9},
     }
 

@@ -296,11 +296,13 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         }
       }
     };
-#if defined(BH_LONG_AHEAD)  // trips the long-row stream requests ahead (tuning experiments only)
-    constexpr int AHEAD = TT == 0 ? BH_LONG_AHEAD : 1;
-#else
-    constexpr int AHEAD = 1;
+#ifndef BH_LONG_AHEAD  // trips the stream requests ahead: without / with GEBV (tuning experiments only)
+#define BH_LONG_AHEAD 1
 #endif
+#ifndef BH_SHORT_AHEAD
+#define BH_SHORT_AHEAD 1
+#endif
+    constexpr int AHEAD = TT == 0 ? BH_LONG_AHEAD : BH_SHORT_AHEAD;
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
       uint4 dg[VPT][NT][3];

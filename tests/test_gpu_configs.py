@@ -447,7 +447,8 @@ def test_many_long_rows_stream_mask_role(layout, mode, M, rng):
         packed = eng.pack(eng.upload_population(pool.reshape(E * NP, M, 2)))
         d_idx = torch.from_numpy(idx).to(eng.device)
         key, ref_key = co.key_from_seed(31).copy(), co.key_from_seed(31)
-        for gen in range(3):
+        for gen in range(4):
+            eng.set_mask_prefetch(gen != 3)  # the last generation makes its masks in stream order (mask_kernel<4>)
             outp = eng.empty_packed(E * n)
             ob = eng.empty_population(E * n) if gen != 1 else None
             g = eng.empty((E, n, 1), torch.float32)
