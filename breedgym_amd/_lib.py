@@ -12,7 +12,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 LIB_PATH = _PKG / "libbreedhip.so"
-_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "index_kernels.h", "select_kernels.h", "gebv_mfma.h", "gebv_bits.h", "mask_stream.h", "threefry.h")] + [
+_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "index_kernels.h", "select_kernels.h", "gebv_mfma.h", "gebv_bits.h", "mask_stream.h", "mutation.h", "threefry.h")] + [
     _ROOT / "include" / "breedhip.h"
 ]
 
@@ -107,6 +107,7 @@ SIGNATURES = {
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
     "bh_set_threefry_layout": (_int, [_vp, _int]),
+    "bh_set_mutation": (_int, [_vp, _c.c_float]),
     "bh_set_env_window": (_int, [_vp, _i64, _i64]),
     "bh_set_cross_window": (_int, [_vp, _i64, _i64]),
     "bh_key_split": (_int, [_u32p, _i64, _int, _u32p]),

@@ -17,6 +17,7 @@
 #include "gebv_bits.h"
 #include "gebv_mfma.h"
 #include "index_kernels.h"
+#include "mutation.h"
 #include "packed_kernels.h"
 #include "row_kernels.h"
 #include "select_kernels.h"
@@ -67,6 +68,10 @@ struct bh_ctx {
   int64_t z_cap[2] = {0, 0};  // bytes
   uint64_t *d_S = nullptr;    // site words of the stream-per-lane mask role (mask_stream.h)
   int64_t s_cap = 0;          // bytes
+  float mutation = 0.0f;      // bh_set_mutation: chromax's mutation probability (0: off, the hot path)
+  uint32_t mut_thr = 0;       // (bits >> 9) < mut_thr  <=>  uniform_f32(bits) < mutation
+  uint64_t *d_F = nullptr;    // flip words of the keyed gametes (mutation.h)
+  int64_t f_cap = 0;          // bytes
   bool prefetch = true;
   int layout = bh::LAYOUT_ORIGINAL;  // bh_set_threefry_layout
   // sharding windows: this context holds envs [env_offset, env_offset + n_envs) of envs_total, or crosses
@@ -394,6 +399,70 @@ int ensure_sites(bh_ctx *c, int64_t B) {
   BH_HIP(hipMalloc(&c->d_S, (size_t)bytes));
   BH_HIP(hipMemsetAsync(c->d_S, 0, (size_t)bytes, c->stream));
   c->s_cap = bytes;
+  return BH_OK;
+}
+
+// mutation (mutation.h): draw the flips of the call's keyed gametes and XOR them into the offspring rows the cross
+// launch just wrote.  B keyed crosses; `rows` offspring rows of `n_out` per env.
+int mutate_rows(bh_ctx *c, uint32_t key0, uint32_t key1, int64_t nkeys, KeyWindow kw, int64_t B, bool dh, bool shared,
+                int64_t rows, int64_t n_out, uint16_t *d_out_packed, uint8_t *d_out_bytes) {
+  const int32_t half = c->layout == bh::LAYOUT_PARTITIONABLE ? (int32_t)c->M : (int32_t)((c->M + 1) / 2);
+  const int32_t wl = (half + 63) / 64;
+  const int64_t fpitch = 2 * (int64_t)wl + 1, streams = dh ? B : 2 * B;
+  const int64_t bytes = streams * fpitch * 8;
+  if (c->f_cap < bytes) {
+    BH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_F) BH_HIP(hipFree(c->d_F));
+    c->d_F = nullptr;
+    c->f_cap = 0;
+    BH_HIP(hipMalloc(&c->d_F, (size_t)bytes));
+    c->f_cap = bytes;
+  }
+  BH_HIP(hipMemsetAsync(c->d_F, 0, (size_t)bytes, c->stream));  // the pad word of every stream
+  bh::MutationParams sp{};
+  sp.F = c->d_F;
+  sp.fpitch = fpitch;
+  sp.M = (int32_t)c->M;
+  sp.half = half;
+  sp.wl = wl;
+  sp.n_streams = (int32_t)streams;
+  sp.key0 = key0;
+  sp.key1 = key1;
+  sp.nkeys = (uint32_t)nkeys;
+  sp.key_offset = (uint32_t)kw.off;
+  sp.dh = dh;
+  sp.layout = c->layout;
+  sp.thr = c->mut_thr;
+  for (int64_t s0 = 0; s0 < streams; s0 += 32768) {  // grid.y holds 65535
+    const int64_t ns = std::min<int64_t>(32768, streams - s0);
+    bh::MutationParams q = sp;
+    q.F = sp.F + s0 * fpitch;
+    // stream s0 + y: advance the key index by s0 streams (s0 is even: gamete parity is kept)
+    q.key_offset = (uint32_t)(kw.off + (dh ? s0 : s0 / 2));
+    hipLaunchKernelGGL(bh::mutation_sites_kernel, dim3((unsigned)std::min(64, (wl + 3) / 4), (unsigned)ns), dim3(256), 0,
+                       c->stream, q);
+    BH_HIP(hipGetLastError());
+  }
+  bh::MutationApplyParams ap{};
+  ap.F = c->d_F;
+  ap.fpitch = fpitch;
+  ap.M = (int32_t)c->M;
+  ap.half = half;
+  ap.wl = wl;
+  ap.n_rows = (int32_t)rows;
+  ap.n_out = (int32_t)n_out;
+  ap.shared = shared;
+  ap.dh = dh;
+  ap.outp = d_out_packed;
+  ap.ppitch = 8 * (int64_t)c->nw;
+  ap.outb = d_out_bytes;
+  ap.bpitch = c->pitch;
+  const int64_t threads = rows * ((c->M + 7) / 8);
+  if (threads > 0) {
+    if ((threads + 255) / 256 > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "mutation: too many rows for one launch");
+    hipLaunchKernelGGL(bh::mutation_apply_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, ap);
+    BH_HIP(hipGetLastError());
+  }
   return BH_OK;
 }
 
@@ -844,6 +913,7 @@ int bh_destroy(bh_ctx *c) {
     if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->d_S) (void)hipFree(c->d_S);
+  if (c->d_F) (void)hipFree(c->d_F);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
   if (c->d_ctrB) (void)hipFree(c->d_ctrB);
@@ -1013,7 +1083,10 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     const bool long_stream = packed && (!c->prefetch || mask_waves_for_runahead(c, B) == 4) && long_row_turns(c, rows) > 1;
     const bool mfma_after =
         d_gebv && (packed ? (c->T >= kMfmaGebvMinTraits ? use_bits_gebv(c, rows) : long_stream) : use_mfma_gebv(c, rows));
-    const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
+    // mutation flips alleles after the crossover: the GEBV (and the reward) must see the mutated rows, so they
+    // come from passes behind mutate_rows
+    const bool mutate = c->mut_thr != 0;
+    const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after && !mutate;
     const int tcount = fused ? (int32_t)c->T : 0;
     // run ahead: the next generation's masks need only the advanced key and the batch size, so
     // the same launch makes them (mask role) while it streams this generation (row role)
@@ -1116,6 +1189,9 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       c->pf.off = kw.off;
       c->pf.total = kw.total;
     }
+    if (mutate)
+      if (int rc2 = mutate_rows(c, sim_key[0], sim_key[1], nkeys, kw, B, dh, shared, rows, n_out, d_out_packed, d_out_bytes))
+        return rc2;
     if (d_gebv && !fused) {
       if (packed)
         rc = mfma_after ? gebv_bits(c, d_out_packed, rows, nullptr, rows, d_gebv)
@@ -1531,6 +1607,15 @@ int bh_set_threefry_layout(bh_ctx *c, int layout) {
   if (!layout_ok(layout)) return fail(BH_ERR_BAD_ARG, "bh_set_threefry_layout: unknown layout %d", layout);
   if (layout != c->layout) c->pf.valid = false;  // masks made ahead belong to the other bit stream
   c->layout = layout;
+  return BH_OK;
+}
+
+int bh_set_mutation(bh_ctx *c, float probability) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  if (!(probability >= 0.0f && probability <= 1.0f))
+    return fail(BH_ERR_BAD_ARG, "bh_set_mutation: probability must be in [0, 1]");
+  c->mutation = probability;
+  c->mut_thr = bh::threshold23(probability);
   return BH_OK;
 }
 

@@ -392,6 +392,11 @@ class HipEngine(EngineBase):
         _lib.check(self._L.bh_set_threefry_layout(self._h, code))
         self.threefry_layout = "partitionable" if code else "original"
 
+    def set_mutation(self, probability: float) -> None:
+        """chromax's ``Simulator(mutation=p)``: every gamete allele flips with probability p (0: off)."""
+        _lib.check(self._L.bh_set_mutation(self._h, float(probability)))
+        self.mutation = float(probability)
+
     def set_env_window(self, env_offset: int, envs_total: int) -> None:
         """This engine's envs are envs [env_offset, ..) of envs_total: founder draws, selection shuffles and
         independent crossover keys are those of the whole (include/breedhip.h, "sharding windows")."""

@@ -56,8 +56,8 @@ class Simulator:
         threefry_layout: str = "original",
         engine=None,
     ):
-        if mutation != 0.0:
-            raise NotImplementedError("mutation > 0 is outside the accelerated hot path")
+        if not 0.0 <= float(mutation) <= 1.0:
+            raise ValueError("mutation is a probability")
         gm = genetic_map if isinstance(genetic_map, GeneticMap) else read_genetic_map(
             genetic_map, trait_names, chr_column, position_column, recombination_column
         )
@@ -77,6 +77,8 @@ class Simulator:
                 engine.set_threefry_layout(threefry_layout)
         else:
             self.engine = HipEngine(gm.recombination_vec, gm.marker_effects, device, threefry_layout)
+        if mutation != 0.0:  # chromax's per-allele flip probability; 0 keeps the fused launch
+            self.engine.set_mutation(mutation)
         self.device = self.engine.device
         self.GEBV_model = TraitModel(self, gm.marker_effects)
         if seed is None:

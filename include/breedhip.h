@@ -212,6 +212,13 @@ int bh_set_cross_window(bh_ctx *ctx, int64_t cross_offset, int64_t crosses_total
 /* Which threefry layout the device paths of a context follow (bh_cross*, bh_founders_device,
  * bh_selection_actions); default BH_THREEFRY_ORIGINAL.  Masks made ahead are dropped on a change. */
 int bh_set_threefry_layout(bh_ctx *ctx, int layout);
+/* chromax's mutation probability -- `Simulator(mutation=p)`, which the reference forwards through **kwargs
+ * (breedgym/vector/vec_env.py:39,45, breedgym/breedgym.py:74-80).  [EXTERNAL/UNVERIFIED, like the meiosis: chromax
+ * is not in the reference tree]  Inside `_meiosis` the gamete key is split into (rec_key, mut_key); every allele of
+ * the finished gamete is flipped where uniform(mut_key, (M,)) < p.  0 (the default) is the hot path; with p > 0
+ * bh_cross* draw the flips and apply them to every output of the call (bit planes, byte layout), and GEBV / reward
+ * are computed from the mutated rows by passes of their own.  Crossover masks and key chains do not change. */
+int bh_set_mutation(bh_ctx *ctx, float probability);
 /* jax.random.split(key, num) -> out (num, 2); `layout`: bh_threefry_layout. */
 int bh_key_split(const uint32_t key[2], int64_t num, int layout, uint32_t *out);
 /* jax.random.permutation(key, n) -> out (n) int32. */

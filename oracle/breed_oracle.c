@@ -214,10 +214,18 @@ int64_t bo_norm_index(int64_t i, int64_t n) {
 int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
              int64_t n_out, int64_t M, const float *r, uint32_t key[2],
              int rng_mode, uint8_t *out, uint8_t *masks) {
+  return bo_cross_mutation(pool, E, n_pool, idx, n_out, M, r, key, rng_mode, 0.0f, out, masks);
+}
+
+int bo_cross_mutation(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
+                      int64_t n_out, int64_t M, const float *r, uint32_t key[2],
+                      int rng_mode, float mutation, uint8_t *out, uint8_t *masks) {
   /* [EXTERNAL/UNVERIFIED] chromax.Simulator.cross key plumbing:
    *   keys = split(sim_key, 2*B + 1); sim_key <- keys[0];
    *   gamete (b, p) uses keys[1 + 2*b + p];
-   *   inside meiosis: rec_key = split(gamete_key, 2)[0].
+   *   inside meiosis: rec_key, mut_key = split(gamete_key, 2);
+   *   gamete ^= bernoulli(mut_key, mutation, (M,)) = uniform(mut_key, (M,)) < mutation   (Simulator(mutation=p),
+   *   forwarded by the reference through **kwargs: vec_env.py:39,45; 0 by default, then no draw changes anything).
    * B = n_out when the key is shared by all envs (the masks are then computed
    * once per cross slot and applied to every env, as the reference's vmapped
    * graph does), E*n_out otherwise. */
@@ -236,11 +244,18 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
 
   /* pass 1: the 2*B crossover masks */
   uint8_t *mk = (uint8_t *)malloc((size_t)(2 * B * M > 0 ? 2 * B * M : 1));
+  uint8_t *mt = mutation > 0.0f ? (uint8_t *)malloc((size_t)(2 * B * M > 0 ? 2 * B * M : 1)) : NULL;
 #pragma omp parallel for schedule(static)
   for (int64_t g = 0; g < 2 * B; ++g) {
     uint32_t two[4];
     bo_split(&keys[2 * (1 + (dh ? g / 2 : g))], 2, two);
     bo_meiosis_mask(two, r, M, mk + g * M); /* two[0..1] = rec key */
+    if (mt) { /* two[2..3] = mut key */
+      uint32_t *bits = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(M > 0 ? M : 1));
+      bo_random_bits(&two[2], M, bits);
+      for (int64_t m = 0; m < M; ++m) mt[g * M + m] = bo_uniform_f32(bits[m]) < mutation;
+      free(bits);
+    }
   }
 
   /* pass 2: gather the parents through idx and pick the alleles the masks name */
@@ -254,10 +269,15 @@ int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
       const uint8_t *par = pool + (e * n_pool + bo_norm_index(idx[2 * c + p], n_pool)) * row;
       uint8_t *o = out + c * row;
       for (int64_t m = 0; m < M; ++m) o[2 * m + p] = par[2 * m + mask[m]];
+      if (mt) {
+        const uint8_t *flip = mt + (2 * b + p) * M;
+        for (int64_t m = 0; m < M; ++m) o[2 * m + p] ^= flip[m];
+      }
       if (masks) memcpy(masks + (2 * c + p) * M, mask, (size_t)M);
     }
   }
   free(mk);
+  free(mt);
   free(keys);
   return 0;
 }

@@ -83,6 +83,11 @@ int64_t bo_norm_index(int64_t i, int64_t n);
 int bo_cross(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
              int64_t n_out, int64_t M, const float *r, uint32_t key[2],
              int rng_mode, uint8_t *out, uint8_t *masks);
+/* The same with chromax's mutation probability [EXTERNAL/UNVERIFIED]: every gamete allele is flipped where
+ * uniform(mut_key, (M,)) < mutation, mut_key = split(gamete_key, 2)[1].  `masks` stay the crossover masks. */
+int bo_cross_mutation(const uint8_t *pool, int64_t E, int64_t n_pool, const int32_t *idx,
+                      int64_t n_out, int64_t M, const float *r, uint32_t key[2],
+                      int rng_mode, float mutation, uint8_t *out, uint8_t *masks);
 
 /* GEBV[i,t] = sum_m (pop[i,m,0] + pop[i,m,1]) * effects[m,t]
  * (scripts/optimize_diff_cross.py:16-17, utils/index_functions.py:55).

@@ -122,7 +122,7 @@ def meiosis_mask(rec_key, r) -> np.ndarray:
     return out[: len(r)]
 
 
-def cross(pool, idx, r, key, rng_mode: int = 0, return_masks: bool = False):
+def cross(pool, idx, r, key, rng_mode: int = 0, return_masks: bool = False, mutation: float = 0.0):
     """pool (E,n_pool,M,2) u8/bool; idx (E,n_out,2) -> (out (E,n_out,M,2) u8, new_key[, masks])."""
     pool = np.ascontiguousarray(pool).view(np.uint8) if pool.dtype == np.bool_ else np.ascontiguousarray(pool, np.uint8)
     if pool.ndim == 3:
@@ -138,9 +138,9 @@ def cross(pool, idx, r, key, rng_mode: int = 0, return_masks: bool = False):
     k = _key(key)
     out = np.empty((E, n_out, M, 2), np.uint8)
     masks = np.empty((E, n_out, 2, M), np.uint8) if return_masks else None
-    rc = lib().bo_cross(
+    rc = lib().bo_cross_mutation(
         _p(pool, _u8p), c_i64(E), c_i64(n_pool), _p(idx, _i32p), c_i64(n_out), c_i64(M),
-        _p(r, _f32p), _p(k, _u32p), ctypes.c_int(rng_mode), _p(out, _u8p),
+        _p(r, _f32p), _p(k, _u32p), ctypes.c_int(rng_mode), ctypes.c_float(mutation), _p(out, _u8p),
         _p(masks, _u8p) if return_masks else None,
     )
     if rc != 0:

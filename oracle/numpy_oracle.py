@@ -101,15 +101,18 @@ def founders(env_key, E, N, n):
     return idx, keys[0].copy()
 
 
-def meiosis(individual, r, gamete_key):
+def meiosis(individual, r, gamete_key, mutation=0.0):
     """[EXTERNAL/UNVERIFIED] chromax.functional._meiosis: (M,2) -> gamete (M,)."""
-    rec_key = split(gamete_key, 2)[0]
+    rec_key, mut_key = split(gamete_key, 2)
     sites = uniform(rec_key, len(r)) < r
     mask = np.logical_xor.accumulate(sites).astype(np.int8)
-    return np.take_along_axis(individual, mask[:, None], axis=-1)[:, 0], mask
+    gamete = np.take_along_axis(individual, mask[:, None], axis=-1)[:, 0]
+    if mutation > 0:  # jax.random.bernoulli(mut_key, p, (M,)) = uniform(mut_key, (M,)) < p, xor-ed into the gamete
+        gamete = gamete ^ (uniform(mut_key, len(r)) < np.float32(mutation)).astype(gamete.dtype)
+    return gamete, mask
 
 
-def cross(parents, r, sim_key):
+def cross(parents, r, sim_key, mutation=0.0):
     """[EXTERNAL/UNVERIFIED] chromax.Simulator.cross on materialised parents (n,2,M,2).
 
     Returns (offspring (n,M,2), new_sim_key, masks (n,2,M))."""
@@ -119,11 +122,11 @@ def cross(parents, r, sim_key):
     masks = np.empty((n, 2, parents.shape[2]), np.uint8)
     for i in range(n):
         for p in range(2):
-            out[i, :, p], masks[i, p] = meiosis(parents[i, p], r, keys[1 + 2 * i + p])
+            out[i, :, p], masks[i, p] = meiosis(parents[i, p], r, keys[1 + 2 * i + p], mutation)
     return out, keys[0].copy(), masks
 
 
-def vec_step_cross(populations, actions, r, sim_key, rng_mode=0):
+def vec_step_cross(populations, actions, r, sim_key, rng_mode=0, mutation=0.0):
     """vec_env.py:88-91: gather parents, then vmap(cross) over envs.
 
     rng_mode 0 reproduces vmap over an un-batched simulator key: every env gets the
@@ -137,10 +140,10 @@ def vec_step_cross(populations, actions, r, sim_key, rng_mode=0):
     if rng_mode == 0:
         outs, newkey = [], None
         for e in range(E):
-            o, newkey, _ = cross(parents[e], r, sim_key)
+            o, newkey, _ = cross(parents[e], r, sim_key, mutation)
             outs.append(o)
         return np.stack(outs), newkey
-    flat, newkey, _ = cross(parents.reshape(E * n, 2, *parents.shape[3:]), r, sim_key)
+    flat, newkey, _ = cross(parents.reshape(E * n, 2, *parents.shape[3:]), r, sim_key, mutation)
     return flat.reshape(E, n, *flat.shape[1:]), newkey
 
 

@@ -24,6 +24,10 @@ class OracleEngine(EngineBase):
         self.threefry_layout = "original"
         self.env_window = (0, 0)
         self.cross_window = (0, 0)
+        self.mutation = 0.0
+
+    def set_mutation(self, probability):
+        self.mutation = float(probability)
 
     def set_threefry_layout(self, layout):
         self.threefry_layout = layout
@@ -42,13 +46,14 @@ class OracleEngine(EngineBase):
         if not total and self.env_window[1]:
             off, total = self.env_window[0] * n_out, self.env_window[1] * n_out
         if not (rng_mode & 1) or not total:
-            return co.cross(p, idx, self.r, key, rng_mode)
+            return co.cross(p, idx, self.r, key, rng_mode, mutation=self.mutation)
         assert n_envs * n_out + off <= total
         flat = np.zeros((1, total, 2), np.int32)
         # one flat batch: env e's pool rows are offset by e * pool_rows
         pool_rows = p.shape[1]
         flat[0, off : off + n_envs * n_out] = (idx + (np.arange(n_envs) * pool_rows)[:, None, None]).reshape(-1, 2)
-        o, newkey = co.cross(p.reshape(1, n_envs * pool_rows, *p.shape[2:]), flat, self.r, key, rng_mode)
+        o, newkey = co.cross(p.reshape(1, n_envs * pool_rows, *p.shape[2:]), flat, self.r, key, rng_mode,
+                              mutation=self.mutation)
         return o[0, off : off + n_envs * n_out].reshape(n_envs, n_out, *o.shape[2:]), newkey
 
     def _g(self, rows_t):  # (rows, pitch) -> (rows, M, 2) numpy u8

@@ -207,8 +207,15 @@ def test_simulator_surface(data, tmp_path):
     assert d.tolist() == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]
     np.save(tmp_path / "pop.npy", geno)
     assert np.array_equal(np.asarray(sim.load_population(tmp_path / "pop.npy")), geno)
-    with pytest.raises(NotImplementedError):
-        Simulator(genetic_map=gm, mutation=0.1, engine=OracleEngine(gm.recombination_vec, gm.marker_effects))
+    # Simulator(mutation=p): chromax's keyword, forwarded by the reference through **kwargs (vec_env.py:39,45)
+    with pytest.raises(ValueError):
+        Simulator(genetic_map=gm, mutation=1.1, engine=OracleEngine(gm.recombination_vec, gm.marker_effects))
+    msim = Simulator(genetic_map=gm, mutation=0.1, seed=3, engine=OracleEngine(gm.recombination_vec, gm.marker_effects))
+    assert msim.mutation == 0.1 and msim.engine.mutation == 0.1
+    moff = msim.cross(parents)
+    mexp, _ = co.cross(geno.view(np.uint8)[None], np.array([[[0, 1], [2, 3], [4, 4]]], np.int32), gm.recombination_vec,
+                       co.key_from_seed(3), 0, mutation=0.1)
+    assert np.array_equal(np.asarray(moff).view(np.uint8), mexp[0]) and not np.array_equal(mexp, exp)
     with pytest.raises(ValueError):
         sim.cross(np.zeros((3, 2, M + 1, 2), bool))
 

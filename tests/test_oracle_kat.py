@@ -148,6 +148,55 @@ def test_c_equals_numpy_random_shapes(rng):
             assert np.array_equal(sel.transpose(0, 1, 3, 2), oc)
 
 
+@pytest.mark.parametrize("layout", ["original", "partitionable"])
+def test_mutation_c_equals_numpy(layout, rng):
+    """chromax's Simulator(mutation=p) [EXTERNAL/UNVERIFIED]: alleles flip where uniform(mut_key) < p, mut_key the
+    second half of split(gamete_key, 2).  The two restatements agree; p = 0 is the plain cross; crossover masks and
+    key chains do not depend on p; the flips are exactly uniform(mut_key) < p; the flip rate is p."""
+    co.set_threefry_layout(layout)
+    no.set_threefry_layout(layout)
+    try:
+        for M in (1, 2, 63, 64, 65, 129, 1001):
+            E, NP, NO = 2, 5, 4
+            pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+            idx = rng.integers(0, NP, (E, NO, 2), dtype=np.int32)
+            r = (rng.random(M) * 0.1).astype(np.float32)
+            for mode in (0, 1):
+                key = co.key_from_seed(int(rng.integers(0, 2**32)))
+                plain, k0, m0 = co.cross(pool, idx, r, key, mode, return_masks=True)
+                same, _ = co.cross(pool, idx, r, key, mode, mutation=0.0)
+                assert np.array_equal(plain, same)
+                for pm in (0.3, 1.0):
+                    oc, kc, m1 = co.cross(pool, idx, r, key, mode, return_masks=True, mutation=pm)
+                    on, kn = no.vec_step_cross(pool, idx, r, key, mode, mutation=pm)
+                    assert np.array_equal(oc, on) and np.array_equal(kc, kn), (M, mode, pm)
+                    assert np.array_equal(kc, k0) and np.array_equal(m1, m0)
+                    if pm == 1.0:
+                        assert np.array_equal(oc, plain ^ 1)
+                # the flips, from the primitives: gamete (b, p) of the flat batch owns keys[1 + 2 b + p]
+                oc, _ = co.cross(pool, idx, r, key, mode, mutation=0.3)
+                B = NO if mode == 0 else E * NO
+                keys = co.split(key, 2 * B + 1)
+                for c in range(E * NO):
+                    b = c % NO if mode == 0 else c
+                    for p in range(2):
+                        mut_key = co.split(keys[1 + 2 * b + p], 2)[1]
+                        flips = np.array([co.lib().bo_uniform_f32(int(w)) for w in co.random_bits(mut_key, M)]) < np.float32(0.3)
+                        assert np.array_equal(oc.reshape(-1, M, 2)[c, :, p] ^ plain.reshape(-1, M, 2)[c, :, p], flips)
+        # double haploids: one gamete, mutated once, fills both slots
+        pool = rng.integers(0, 2, (1, 4, 200, 2), dtype=np.uint8)
+        one = rng.integers(0, 4, (1, 6), dtype=np.int32)
+        o, _ = co.cross(pool, np.stack((one, one), -1), np.full(200, 0.05, np.float32), co.key_from_seed(2), 3, mutation=0.2)
+        assert np.array_equal(o[..., 0], o[..., 1])
+        # rate
+        pool = np.zeros((1, 1, 4096, 2), np.uint8)
+        o, _ = co.cross(pool, np.zeros((1, 64, 2), np.int32), np.zeros(4096, np.float32), co.key_from_seed(5), 1, mutation=0.01)
+        assert abs(o.mean() - 0.01) < 5 * np.sqrt(0.01 * 0.99 / o.size)
+    finally:
+        co.set_threefry_layout("original")
+        no.set_threefry_layout("original")
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_golden_cross_and_gebv(name):
     c = load_case(name)
