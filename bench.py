@@ -174,9 +174,96 @@ def roofline_of(kernel, nbytes, ms, **extra):
             "frac": achieved / HBM_PEAK_GBPS, "bytes_per_launch": nbytes, "kernel_ms": ms, **extra}
 
 
+_LIVE_TRAFFIC = {}  # kernel name (as rocprofv3 prints it, blanks removed) -> HBM bytes per launch, measured by this run
+_LIVE_NOTE = None
+
+
+def traffic_child():
+    """Child of live_traffic(), run under ``rocprofv3 --pmc``: exactly the launches the roofline objects time
+    (time_cross_launches of the headline env and of configs[2], the two GEBV routes of configs[4]), nothing else."""
+    import torch
+
+    from breedgym_amd import HipEngine, VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    torch.cuda.set_device(0)
+    for (N, M, E, n, chrs, reps, with_gebv) in ((N_GERMPLASM, N_MARKERS, N_ENVS, N_PER_ENV, 10, 30, True),
+                                                (2048, 100_000, 4, 2048, 21, 6, False)):
+        gm = synthetic_genetic_map(M, n_chr=chrs, n_traits=1, seed=1)
+        env = VecBreedGym(num_envs=E, initial_population=synthetic_genotypes(N, M, seed=0), individual_per_gen=n,
+                          num_generations=N_GENERATIONS, autoreset=True, reward_shaping=True, sync_rewards=False, genetic_map=gm)
+        arng = np.random.default_rng(2)
+        actions = [torch.from_numpy(arng.integers(0, n, (E, n, 2), dtype=np.int32)).to(env.device) for _ in range(4)]
+        env.reset(seed=100)
+        time_cross_launches(env, actions, reps, with_gebv=with_gebv)
+        del env
+    N, M, T = 2048, 100_000, 8
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=T, seed=1)
+    eng = HipEngine(gm.recombination_vec, gm.marker_effects)
+    rows = eng.upload_population(synthetic_genotypes(N, M, seed=0))
+    packed = eng.pack(rows)
+    g = eng.empty((N, T), torch.float32)
+    for _ in range(8):
+        eng.gebv(rows, g)
+        eng.gather_packed(packed, None, N, None, None, g)
+    torch.cuda.synchronize()
+
+
+def live_traffic(timeout=240):
+    """HBM-side bytes per launch of the hot kernels, measured by THIS run: two child processes of this script under
+    ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``... --pmc WRITE_SIZE`` (separate passes, the program itself
+    after ``--``; /opt/skills/guides/MI355X_MICROARCH.md, HBM section), started before this process touches the GPU.
+    Correction as the guide prescribes for gfx950: both counters are KiB; FETCH_SIZE reports half the bytes of wide
+    streaming reads -> 2 x FETCH_SIZE + WRITE_SIZE.  Any failure leaves the committed passes as the (named) source."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+
+    global _LIVE_NOTE
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        _LIVE_NOTE = "rocprofv3 not found"
+        return
+    tmp = tempfile.mkdtemp(prefix="bh_pmc_", dir="/tmp")
+    per = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", f"{tmp}/{ctr}", "-o", "p", "--",
+                   sys.executable, str(ROOT / "bench.py"), "--traffic-child"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout)
+            files = glob.glob(f"{tmp}/{ctr}/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                _LIVE_NOTE = f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode})"
+                return
+            acc = defaultdict(list)
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == ctr:
+                    acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            per[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+        for k, (f, nf) in per["FETCH_SIZE"].items():
+            w = per["WRITE_SIZE"].get(k, (0.0, 0))[0]
+            name = k.split("(")[0].replace("void ", "").replace("bh::", "").replace(" ", "")
+            _LIVE_TRAFFIC[name] = ((2.0 * f + w) * 1024.0, nf)
+        _LIVE_NOTE = "ok"
+    except Exception as e:  # a missing counter, a timeout: the committed passes remain
+        _LIVE_NOTE = f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def committed_traffic(kernel_prefix):
-    """PMC traffic (2 x FETCH_SIZE + WRITE_SIZE, per launch) from the committed rocprofv3 passes under
-    profiles/: a measurement of an earlier run of the same command, NOT of this run; the source is named."""
+    """PMC traffic (2 x FETCH_SIZE + WRITE_SIZE, per launch): measured by this run (live_traffic) where that worked,
+    else from the committed rocprofv3 passes under profiles/ -- a measurement of an earlier run of the same command,
+    NOT of this run.  The source is named either way."""
+    want = kernel_prefix.replace(" ", "")
+    for name, (b, n) in _LIVE_TRAFFIC.items():
+        if name.startswith(want):
+            return b, (f"measured by this run: child passes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                       f"(separate), mean of {n} launches of {name}, 2 x FETCH_SIZE + WRITE_SIZE in KiB")
     for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
         f = ROOT / "profiles" / name
         if not f.exists():
@@ -188,7 +275,8 @@ def committed_traffic(kernel_prefix):
         entries = d.get("kernels", [d])
         for e in entries:
             if str(e.get("kernel", "")).replace(" ", "").startswith(kernel_prefix.replace(" ", "")):
-                return e.get("hbm_bytes_per_launch"), f"profiles/{name} (rocprofv3 --pmc passes of an earlier run; not measured by this run)"
+                return e.get("hbm_bytes_per_launch"), (f"profiles/{name} (rocprofv3 --pmc passes of an earlier run; not measured "
+                                                       f"by this run: {_LIVE_NOTE or 'live passes not requested'})")
     return None, "none: no committed PMC pass for this kernel"
 
 
@@ -222,7 +310,9 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
                                      "per lane -- 2048 keyed crosses x 100k markers of Threefry; then site words -> masks)",
                                      nbytes + 2 * 4 * n * (M // 128 + 2) * 8, kms,  # + site words written and read back
                                      api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
-             "traffic": committed_traffic("packed_long_kernel")[0] if obs == "eager" else None,
+             # both kernels of the timed pair; the PMC passes are of the eager configuration
+             "traffic": (committed_traffic("packed_long_kernel")[0] or 0) + (committed_traffic("mask_finish_kernel")[0] or 0)
+                        if obs == "eager" and committed_traffic("packed_long_kernel")[0] else None,
              "traffic_source": committed_traffic("packed_long_kernel")[1] if obs == "eager" else None,
              "gebv_pass_ms": kms_all - kms,
              "gebv_pass_note": "gebv_bits_kernel + gebv_finish_kernel over the bit-plane offspring (0.2 GB)",
@@ -340,13 +430,24 @@ def main():
                          "(profiling runs, so that a kernel name in the profile is one configuration)")
     ap.add_argument("--only", choices=("c3", "c3lazy", "c5"), default=None,
                     help="run only that extra configuration (profiling runs: one configuration per kernel name)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not spawn the rocprofv3 --pmc child passes behind roofline.traffic (committed passes are named instead)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.traffic_child:
+        traffic_child()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+
+    # HBM traffic of the hot kernels from PMC counters, by child processes, BEFORE this process initialises the GPU
+    if (world == 1 and args.mode == "envs" and not args.headline_only and args.only is None and not args.no_live_traffic
+            and "RANK" not in os.environ):
+        live_traffic()
 
     import torch
     import torch.distributed as dist
