@@ -11,7 +11,7 @@ int main(int argc, char **argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0, obs = argc > 2 ? atoi(argv[2]) : 1, wg = argc > 3 ? atoi(argv[3]) : 1;
   const int64_t M = argc > 4 ? atoll(argv[4]) : 10000, E = argc > 5 ? atoll(argv[5]) : 16, n = argc > 6 ? atoll(argv[6]) : 256;
   const int rew = argc > 7 ? atoi(argv[7]) : 0;  // 1: with the per-env reward noted in the launch
-  const int reps = 50;
+  const int reps = getenv("AB_REPS") ? atoi(getenv("AB_REPS")) : 50;  // long runs: clock / power sampling from outside
   std::vector<float> r(M, 0.0015f), eff(M, 1.0f);
   for (int64_t m = 0; m < M; m += M / 10) r[m] = 0.5f;
   bh_ctx *ctx;
