@@ -285,6 +285,12 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         v = v < last ? v : last;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+#if defined(BH_ABLATE_NO_LOADS)  // timing experiments only: the stream's stores without its loads
+          w.a[u][r] = (uint32_t)v * 2654435761u >> 16;
+          w.b[u][r] = (uint32_t)v * 40503u & 0xffffu;
+          w.z[u][r] = (uint32_t)v * 9973u & 0xffffu;
+          continue;
+#endif
           w.a[u][r] = word_at(src0[r], (uint32_t)v);
           if constexpr (MODE == MODE_CROSS) {
             w.b[u][r] = word_at(src1[r], (uint32_t)v);
@@ -335,9 +341,14 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           const int vu = v + 64 * u < last ? v + 64 * u : last;
           uint32_t o = w.a[u][r];
           if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
+#if defined(BH_ABLATE_NO_STORES)  // timing experiments only: the stream's loads without its stores
+          if (o == 0x12345u) *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
+          const uint4 oo = expand_vector(o);
+#else
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
           const uint4 oo = expand_vector(o);
           if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo;
+#endif
           if constexpr (TT > 0) {
             if (has) {  // a lane that redid the last vector must not count it twice
               typedef short short2v __attribute__((ext_vector_type(2)));
@@ -500,20 +511,35 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 // No LDS, no barrier; the two kinds of wave never wait for each other.  More mask waves than row waves: the
 // Threefry chains of a wave leave issue slots that only other waves can fill, and the workgroups of a grid of
 // rows / (4 R seq) are few enough to be resident all at once (no tail of late workgroups doing mask work alone).
+}  // namespace bh
+#include "packed_dma.h"
+namespace bh {
+
 template <int R, int MASK_WAVES>
 __global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(const PackedParams rp, const MaskParams mp) {
   prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if !defined(BH_LONG_NO_DMA)
+  static_assert(R == 1, "the LDS-DMA stream takes one row per turn");
+  __shared__ __attribute__((aligned(16))) char ring[4][kDmaRingBytes];  // one ring per row wave (packed_dma.h)
+#endif
 #if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only
   if (wave < 4) return;
 #elif defined(BH_ABLATE_NO_MASKROLE)
   if (wave >= 4) return;
 #endif
   if (wave < 4) {
+#if !defined(BH_LONG_NO_DMA)
+    if (rp.outb)
+      packed_dma_role<true>(rp, (int)blockIdx.x, wave, ring[wave]);
+    else
+      packed_dma_role<false>(rp, (int)blockIdx.x, wave, ring[wave]);
+#else  // tuning experiments only: the register-staged stream
     if (rp.outb)
       packed_stream_role<0, MODE_CROSS, R, true, kLongRowVectors>(rp, (int)blockIdx.x, wave);
     else
       packed_stream_role<0, MODE_CROSS, R, false, kLongRowVectors>(rp, (int)blockIdx.x, wave);
+#endif
   } else {
     mask_stream_role(mp, (int)blockIdx.x * MASK_WAVES + wave - 4, (int)gridDim.x * MASK_WAVES);
   }

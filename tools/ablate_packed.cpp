@@ -24,7 +24,10 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> h(rows * pitch);
   { uint64_t s = 88172645463325252ull; uint64_t *w = reinterpret_cast<uint64_t *>(h.data());
     for (size_t i = 0; i < h.size() / 8; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; w[i] = s & 0x0101010101010101ull; } }
-  std::vector<int32_t> hi(rows * 2); for (auto &v : hi) v = rand() % n;
+  // AB_POOL=k: all parents among the first k rows of every env's pool (a cache-resident pool: what the loads cost
+  // when they do not go to HBM)
+  const int npick = getenv("AB_POOL") ? atoi(getenv("AB_POOL")) : (int)n;
+  std::vector<int32_t> hi(rows * 2); for (auto &v : hi) v = rand() % npick;
   bh_memcpy_h2d(ctx, bytes, h.data(), h.size()); bh_memcpy_h2d(ctx, idx, hi.data(), hi.size() * 4);
   bh_pack(ctx, bytes, rows, pool); bh_sync(ctx);
   float *rw[2] = {nullptr, nullptr};
