@@ -420,6 +420,10 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   }
 }
 
+}  // namespace bh
+#include "packed_dma.h"
+namespace bh {
+
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   __shared__ RewardLds rwl;
@@ -429,6 +433,19 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
     __syncthreads();
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
+#if !defined(BH_LONG_NO_DMA)
+  if constexpr (TT == 0 && R == 1) {
+    // long rows in turns (the founder gather of a reset, a cross without run-ahead): the LDS-DMA stream
+    if (p.outp && p.seq > 1) {
+      __shared__ __attribute__((aligned(16))) char ring[4][MODE == MODE_CROSS ? kDmaRingBytes : kDmaGatherRingBytes];
+      if (p.outb)
+        packed_dma_role<MODE, true>(p, (int)blockIdx.x, wave, ring[wave]);
+      else
+        packed_dma_role<MODE, false>(p, (int)blockIdx.x, wave, ring[wave]);
+      return;
+    }
+  }
+#endif
   if constexpr (TT <= 2) {
     // packed rows out (reset's founder gather, a cross without run-ahead): the pipelined stream; without
     // GEBV only where the host asks for it (p.seq > 1: long rows in turns)
@@ -511,10 +528,6 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 // No LDS, no barrier; the two kinds of wave never wait for each other.  More mask waves than row waves: the
 // Threefry chains of a wave leave issue slots that only other waves can fill, and the workgroups of a grid of
 // rows / (4 R seq) are few enough to be resident all at once (no tail of late workgroups doing mask work alone).
-}  // namespace bh
-#include "packed_dma.h"
-namespace bh {
-
 template <int R, int MASK_WAVES>
 __global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(const PackedParams rp, const MaskParams mp) {
   prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
@@ -531,9 +544,9 @@ __global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(cons
   if (wave < 4) {
 #if !defined(BH_LONG_NO_DMA)
     if (rp.outb)
-      packed_dma_role<true>(rp, (int)blockIdx.x, wave, ring[wave]);
+      packed_dma_role<MODE_CROSS, true>(rp, (int)blockIdx.x, wave, ring[wave]);
     else
-      packed_dma_role<false>(rp, (int)blockIdx.x, wave, ring[wave]);
+      packed_dma_role<MODE_CROSS, false>(rp, (int)blockIdx.x, wave, ring[wave]);
 #else  // tuning experiments only: the register-staged stream
     if (rp.outb)
       packed_stream_role<0, MODE_CROSS, R, true, kLongRowVectors>(rp, (int)blockIdx.x, wave);
