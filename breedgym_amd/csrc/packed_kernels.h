@@ -56,6 +56,7 @@ struct PackedParams {
   float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
   int64_t reward_pitch;  // floats between the words of two envs in both (RowParams)
   int32_t n_envs;
+  int32_t ring_off;  // packed_quarter_role: byte offset of the row waves' LDS rings in the dynamic LDS
 };
 
 // dword k of byte-layout vector v from its packed word: bits 4k .. 4k+3 are its four bytes; the
@@ -323,6 +324,10 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
             dg[u][q][0] = dp[0];
             dg[u][q][1] = dp[1];
             dg[u][q][2] = dp[2];
+#elif defined(BH_ABLATE_NO_DIGITS)  // timing experiments only: the stream without its effect-digit loads
+            dg[u][q][0] = make_uint4(vu, 1, 2, 3);
+            dg[u][q][1] = make_uint4(3, vu, 2, 1);
+            dg[u][q][2] = make_uint4(1, 2, vu, 3);
 #else  // one plane per digit: a wave's load is 1 KB contiguous
             const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vu;
             dg[u][q][0] = dp[0];
@@ -467,12 +472,19 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 // fp.out != null (MW = 4 only): the last fp.E workgroups of the grid draw the founders of the reset that follows
 // this step (founders_role): 12 us of LDS sorting by 16 workgroups that would otherwise be a launch of its own
 // between the horizon step and the founder gather.
-template <int TT, int MW, int R>
+}  // namespace bh
+#include "packed_quarter.h"
+namespace bh {
+
+// QNU > 0 (TT = 1, MW = 4): the row role is packed_quarter_role<QNU> (packed_quarter.h: short rows cut into marker
+// quarters, every load ahead of every store); R then only names the grid (4 R = eight rows per workgroup).
+template <int TT, int MW, int R, int QNU = 0>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp,
                                                           const FoundersParams fp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
+  __shared__ QuarterLds qlds;
   if constexpr (MW == 4) {
     if (fp.out && (int)blockIdx.x >= (int)gridDim.x - fp.E) {  // uniform per workgroup
       founders_role(fp, (int)blockIdx.x - ((int)gridDim.x - fp.E), reinterpret_cast<uint64_t *>(lds_raw));
@@ -486,6 +498,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
       counter = 0;
       done = 0;
       reward_lds_init(&rwl);
+      if constexpr (QNU > 0) quarter_lds_init(&qlds);
     }
     __syncthreads();
   }
@@ -496,6 +509,15 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 #endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) {
+      if constexpr (QNU > 0) {
+        static_assert(TT == 1 && MW == 4 && 4 * R == kQuarterRows, "the quarter role: one trait, four-wave mask groups");
+        char *ring = reinterpret_cast<char *>(lds_raw) + rp.ring_off + wave * kQuarterRingBytes;
+        if (rp.outb)
+          packed_quarter_role<QNU, true>(rp, (int)blockIdx.x, wave, ring, &qlds);
+        else
+          packed_quarter_role<QNU, false>(rp, (int)blockIdx.x, wave, ring, &qlds);
+        return;
+      }
 #if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
