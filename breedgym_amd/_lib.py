@@ -12,7 +12,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 LIB_PATH = _PKG / "libbreedhip.so"
-_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "index_kernels.h", "select_kernels.h", "gebv_mfma.h", "gebv_bits.h", "mask_stream.h", "packed_dma.h", "packed_quarter.h", "mutation.h", "threefry.h")] + [
+_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "index_kernels.h", "select_kernels.h", "gebv_mfma.h", "gebv_bits.h", "mask_stream.h", "packed_dma.h", "mutation.h", "threefry.h")] + [
     _ROOT / "include" / "breedhip.h"
 ]
 

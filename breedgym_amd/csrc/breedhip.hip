@@ -303,48 +303,6 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   return BH_OK;
 }
 
-// the fused launch with the quarter row role (packed_quarter.h): one trait in the stream, rows of up to 4 x QNU x 512
-// markers, eight rows per workgroup (the grid of launch_pcross_tt<1, 4, 2>)
-template <int QNU>
-int launch_pquarter(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
-  rp.n_blocks = (rp.n_rows + bh::kQuarterRows - 1) / bh::kQuarterRows;
-  // dynamic LDS of a row workgroup: the mask group's site words, then the four row waves' rings; the workgroups that
-  // draw founders use the same bytes for their sort
-  rp.ring_off = (int32_t)(((size_t)mp.group_lds + 15) & ~(size_t)15);
-  size_t lds = (size_t)rp.ring_off + 4 * (size_t)bh::kQuarterRingBytes;
-  int grid = two_role_grid(rp.n_blocks, mp.n_blocks);
-  bh::FoundersParams fp{};
-  if (c->founders_pending && c->fp_pending.P <= 1024 && (size_t)c->fp_pending.P * 16 <= 48 * 1024) {
-    fp = c->fp_pending;  // the draw rides on this launch: E more workgroups
-    c->founders_pending = false;
-    grid += fp.E;
-    lds = std::max(lds, (size_t)fp.P * 16);
-  }
-  auto kernel = bh::packed_cross_kernel<1, 4, 2, QNU>;
-  if (lds > 64 * 1024) {  // more than 64 KB of dynamic LDS has to be asked for, once per kernel
-    static size_t asked = 0;
-    if (asked < lds) {
-      BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      asked = lds;
-    }
-  }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel (quarter role) launch: %s", hipGetErrorString(e));
-  return BH_OK;
-}
-
-// units of 64 words a row wave of the quarter role owns, or 0 where the role does not apply
-int quarter_units(const bh_ctx *c) {
-#if defined(BH_NO_QUARTER)  // tuning experiments only
-  return 0;
-#else
-  const int units = (int)((c->M + 511) / 512);
-  const int nu = (units + 3) / 4;
-  return nu <= bh::kQuarterMaxUnits ? nu : 0;
-#endif
-}
-
 // the launch for many long rows: stream role in turns + stream-per-lane mask role, then the site words -> masks
 #ifndef BH_LONG_MASK_WAVES  // mask waves per workgroup of four row waves (tuning experiments only)
 #define BH_LONG_MASK_WAVES 8
@@ -1183,15 +1141,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
           rc = launch_pcross_mw<4, kRowsPerWaveLong>(c, p, mp, 0);
 #endif
         }
-        else if (wide && tcount == 1 && c->T == 1 && quarter_units(c) > 0) {
-          switch (quarter_units(c)) {  // every load ahead of every store (packed_quarter.h)
-            case 1: rc = launch_pquarter<1>(c, p, mp); break;
-            case 2: rc = launch_pquarter<2>(c, p, mp); break;
-            case 3: rc = launch_pquarter<3>(c, p, mp); break;
-            case 4: rc = launch_pquarter<4>(c, p, mp); break;
-            default: rc = launch_pquarter<5>(c, p, mp); break;
-          }
-        } else
+        else
           rc = wide ? launch_pcross_mw<4, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<4, 1>(c, p, mp, tt_for(tcount));
       } else if (turns > 1) {

@@ -56,7 +56,6 @@ struct PackedParams {
   float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
   int64_t reward_pitch;  // floats between the words of two envs in both (RowParams)
   int32_t n_envs;
-  int32_t ring_off;  // packed_quarter_role: byte offset of the row waves' LDS rings in the dynamic LDS
 };
 
 // dword k of byte-layout vector v from its packed word: bits 4k .. 4k+3 are its four bytes; the
@@ -472,19 +471,12 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 // fp.out != null (MW = 4 only): the last fp.E workgroups of the grid draw the founders of the reset that follows
 // this step (founders_role): 12 us of LDS sorting by 16 workgroups that would otherwise be a launch of its own
 // between the horizon step and the founder gather.
-}  // namespace bh
-#include "packed_quarter.h"
-namespace bh {
-
-// QNU > 0 (TT = 1, MW = 4): the row role is packed_quarter_role<QNU> (packed_quarter.h: short rows cut into marker
-// quarters, every load ahead of every store); R then only names the grid (4 R = eight rows per workgroup).
-template <int TT, int MW, int R, int QNU = 0>
+template <int TT, int MW, int R>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp,
                                                           const FoundersParams fp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
-  __shared__ QuarterLds qlds;
   if constexpr (MW == 4) {
     if (fp.out && (int)blockIdx.x >= (int)gridDim.x - fp.E) {  // uniform per workgroup
       founders_role(fp, (int)blockIdx.x - ((int)gridDim.x - fp.E), reinterpret_cast<uint64_t *>(lds_raw));
@@ -498,7 +490,6 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
       counter = 0;
       done = 0;
       reward_lds_init(&rwl);
-      if constexpr (QNU > 0) quarter_lds_init(&qlds);
     }
     __syncthreads();
   }
@@ -509,15 +500,6 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
 #endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) {
-      if constexpr (QNU > 0) {
-        static_assert(TT == 1 && MW == 4 && 4 * R == kQuarterRows, "the quarter role: one trait, four-wave mask groups");
-        char *ring = reinterpret_cast<char *>(lds_raw) + rp.ring_off + wave * kQuarterRingBytes;
-        if (rp.outb)
-          packed_quarter_role<QNU, true>(rp, (int)blockIdx.x, wave, ring, &qlds);
-        else
-          packed_quarter_role<QNU, false>(rp, (int)blockIdx.x, wave, ring, &qlds);
-        return;
-      }
 #if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
