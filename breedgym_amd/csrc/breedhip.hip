@@ -67,6 +67,8 @@ struct bh_ctx {
   uint8_t *d_Z[2] = {nullptr, nullptr};
   int64_t z_cap[2] = {0, 0};  // bytes
   uint64_t *d_S = nullptr;    // site words of the stream-per-lane mask role (mask_stream.h)
+  uint16_t *d_pk = nullptr;   // bit planes of byte-layout rows on their way to gebv_bits (gebv_chunks)
+  int64_t pk_cap = 0;         // bytes
   int64_t s_cap = 0;          // bytes
   float mutation = 0.0f;      // bh_set_mutation: chromax's mutation probability (0: off, the hot path)
   uint32_t mut_thr = 0;       // (bits >> 9) < mut_thr  <=>  uniform_f32(bits) < mutation
@@ -619,7 +621,45 @@ bool use_bits_gebv(const bh_ctx *c, int64_t rows) {
 }
 
 // GEBV of rows already in memory, for trait chunks [t_begin, T)
+int launch_pack(bh_ctx *c, const bh::PackParams &p) {
+  for (int64_t r0 = 0; r0 < p.n_rows; r0 += 65535) {  // grid.y holds 65535
+    bh::PackParams q = p;
+    q.src = p.src + r0 * p.pitch;
+    q.dst = p.dst + r0 * p.nvp;
+    q.n_rows = (int32_t)std::min<int64_t>(65535, p.n_rows - r0);
+    hipLaunchKernelGGL(bh::pack_kernel, dim3((unsigned)((p.nvp + 2047) / 2048), (unsigned)q.n_rows), dim3(256), 0, c->stream, q);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+#ifndef BH_GEBV_VIA_BITS_MIN  // rows x markers from which byte-layout rows go through bit planes (tuning experiments only)
+#define BH_GEBV_VIA_BITS_MIN (1ll << 25)
+#endif
 int gebv_chunks(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
+  // large byte-layout populations: to bit planes first (the read of the byte rows at streaming rate, 1/8 of them
+  // written), then the matrix-core pass over those (gebv_bits.h) -- 2048 x 100k x 8: 158 -> 115 us; long rows of one
+  // or two traits: instead of the f64 stream
+  if (t_begin == 0 && use_bits_gebv(c, rows) && rows * c->M >= BH_GEBV_VIA_BITS_MIN) {
+    const int64_t bytes = rows * 16 * c->nw;
+    if (c->pk_cap < bytes) {
+      BH_HIP(hipStreamSynchronize(c->stream));
+      if (c->d_pk) BH_HIP(hipFree(c->d_pk));
+      c->d_pk = nullptr;
+      c->pk_cap = 0;
+      BH_HIP(hipMalloc(&c->d_pk, (size_t)bytes));
+      c->pk_cap = bytes;
+    }
+    bh::PackParams pp{};
+    pp.src = d_pop;
+    pp.dst = c->d_pk;
+    pp.pitch = c->pitch;
+    pp.nvec = c->nvec;
+    pp.nvp = 8 * c->nw;
+    pp.n_rows = (int32_t)rows;
+    if (int rc = launch_pack(c, pp)) return rc;
+    return gebv_bits(c, c->d_pk, rows, nullptr, rows, d_gebv);
+  }
   if (t_begin == 0 && use_mfma_gebv(c, rows)) return gebv_mfma(c, d_pop, rows, d_gebv);
   for (int t0 = t_begin; t0 < c->T; t0 += kMaxFusedTraits) {
     bh::RowParams p = base_params(c);
@@ -913,6 +953,7 @@ int bh_destroy(bh_ctx *c) {
     if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->d_S) (void)hipFree(c->d_S);
+  if (c->d_pk) (void)hipFree(c->d_pk);
   if (c->d_F) (void)hipFree(c->d_F);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);
@@ -1248,9 +1289,7 @@ int bh_pack(bh_ctx *c, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed
   p.nvec = c->nvec;
   p.nvp = 8 * c->nw;
   p.n_rows = (int32_t)n_rows;
-  hipLaunchKernelGGL(bh::pack_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, c->stream, p);
-  BH_HIP(hipGetLastError());
-  return BH_OK;
+  return launch_pack(c, p);
 }
 
 int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,

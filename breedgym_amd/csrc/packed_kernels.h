@@ -570,21 +570,30 @@ struct PackParams {
   int32_t nvec, nvp, n_rows;
 };
 
+// grid (ceil(nvp / 2048), rows): a wave takes 512 consecutive vectors of one row, eight per lane 64 apart (every load a
+// contiguous KB, all eight in flight before the first is used) -- a row is cut over many waves, so that also a few
+// thousand long rows fill the chip (one wave per whole row read 416 MB in 135 us; this reads them in 85)
 __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= p.n_rows) return;
+  const int row = blockIdx.y, lane = threadIdx.x & 63;
+  const int v0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 512 + lane;
+  if (v0 - lane >= p.nvp) return;
   const uint8_t *s = p.src + (int64_t)row * p.pitch;
   uint16_t *d = p.dst + (int64_t)row * p.nvp;
-  for (int v = lane; v < p.nvp; v += 64) {
-    uint32_t o = 0;
-    if (v < p.nvec) {
-      const uint4 w = *reinterpret_cast<const uint4 *>(s + 16 * (int64_t)v);
-      const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
+  uint4 w[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)  // bit 0 of bytes 0..3 -> bits 4k .. 4k+3
-        o |= (((dw[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);
-    }
-    d[v] = (uint16_t)o;
+  for (int u = 0; u < 8; ++u) {
+    const int v = v0 + 64 * u;
+    w[u] = v < p.nvec ? *reinterpret_cast<const uint4 *>(s + 16 * (int64_t)v) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int v = v0 + 64 * u;
+    const uint32_t dw[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)  // bit 0 of bytes 0..3 -> bits 4k .. 4k+3
+      o |= (((dw[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);
+    if (v < p.nvp) d[v] = (uint16_t)o;  // zero words from the last marker up to the pitch
   }
 }
 
