@@ -1,7 +1,7 @@
 """Soak: many generations with the byte-layout and the bit-plane kernels side by side (same seeds),
 compared every generation on the device, and against the CPU oracle every `check` generations.
 Shapes are chosen to go through the run-ahead masks, the mask turns (four waves per cross, more keyed
-crosses than row workgroups) and both key modes."""
+crosses than row workgroups), the long-row launch (LDS-DMA stream, rows in turns) and both key modes."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -48,4 +48,9 @@ bad += soak(16_400, 2, 1100, 0, 60, 10, 3)     # MW = 4, 1100 keyed crosses vs 2
 bad += soak(16_400, 1, 1300, 1, 60, 10, 4)
 bad += soak(50_000, 4, 600, 0, 40, 10, 5)
 bad += soak(1_000, 8, 4100, 1, 60, 10, 6)      # one wave per cross, 32,800 keyed crosses
+# many long rows: the LDS-DMA stream next to the stream-per-lane mask role (rows in turns, 5 / 5 / 9 / 25 chunks per row)
+bad += soak(16_523, 2, 4200, 0, 30, 10, 7)
+bad += soak(20_000, 1, 8200, 1, 20, 10, 8)
+bad += soak(33_000, 4, 2100, 0, 20, 10, 9)
+bad += soak(100_000, 4, 2048, 0, 12, 6, 10)
 sys.exit(1 if bad else 0)
