@@ -209,7 +209,7 @@ def traffic_child():
     torch.cuda.synchronize()
 
 
-def live_traffic(timeout=240):
+def live_traffic(timeout=90):
     """HBM-side bytes per launch of the hot kernels, measured by THIS run: two child processes of this script under
     ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``... --pmc WRITE_SIZE`` (separate passes, the program itself
     after ``--``; /opt/skills/guides/MI355X_MICROARCH.md, HBM section), started before this process touches the GPU.
