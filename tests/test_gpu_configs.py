@@ -140,6 +140,26 @@ def test_c5_multi_trait_gebv_full_shape():
     assert torch.equal(outp, packed[idx.long()])
 
 
+@pytest.mark.parametrize("T", [1, 3])
+@pytest.mark.parametrize("rows,M", [(1024, 32_768), (1024, 32_767), (2050, 16_385), (2047, 16_385), (130, 262_144)])
+def test_byte_row_gebv_on_both_sides_of_the_bit_plane_route(rows, M, T, rng):
+    """bh_gebv on byte-layout rows: populations of 2^25 row x markers and more are packed to bit planes and take the
+    matrix-core pass over those, smaller ones the byte-row kernels -- the same GEBV on both sides of the switch."""
+    from breedgym_amd import HipEngine
+
+    r = np.full(M, 0.01, np.float32)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    geno = rng.integers(0, 2, (rows, M, 2), dtype=np.uint8)
+    eng = HipEngine(r, eff)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    g64 = co.gebv(geno, eff, want64=True)[1]
+    d = eng.upload_population(geno)
+    assert gebv_close(eng.gebv(d).cpu().numpy(), g64)
+    assert gebv_close(eng.gebv(d).cpu().numpy(), g64)  # again: the scratch bit planes are reused
+    # a smaller population through the same engine afterwards (scratch larger than needed)
+    assert gebv_close(eng.gebv(d[: rows // 2].contiguous()).cpu().numpy(), g64[: rows // 2])
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 8])
 @pytest.mark.parametrize("M", [131_072, 200_001])
 def test_same_sign_effects_on_long_rows_do_not_wrap(T, M):
