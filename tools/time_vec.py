@@ -15,7 +15,8 @@ print("E     s/step (mean of 10, synced)   crosses/s")
 for E in (8, 16, 32):
     env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=210, genetic_map=gm)
     env.reset(seed=0)
-    env.step(np.random.randint(0, 210, size=(E, 210, 2)))
+    for _ in range(11):  # a whole episode and its autoreset: every kernel of the loop has been loaded once (the first
+        env.step(np.random.randint(0, 210, size=(E, 210, 2)))  # use of a kernel costs ~50 ms of code-object loading)
     def one():
         env.step(np.random.randint(0, 210, size=(E, 210, 2)))
         torch.cuda.synchronize()
