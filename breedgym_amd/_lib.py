@@ -12,9 +12,13 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 LIB_PATH = _PKG / "libbreedhip.so"
-_SOURCES = [_PKG / "csrc" / n for n in ("breedhip.hip", "row_kernels.h", "packed_kernels.h", "index_kernels.h", "select_kernels.h", "gebv_mfma.h", "gebv_bits.h", "mask_stream.h", "packed_dma.h", "mutation.h", "threefry.h")] + [
-    _ROOT / "include" / "breedhip.h"
-]
+_CSRC = _PKG / "csrc"
+_UNITS = ("breedhip", "cross", "gebv", "select")  # translation units (csrc/ctx.h says what lives where)
+_BUILD = _CSRC / "_build"
+
+
+def _sources():
+    return sorted(_CSRC.glob("*.hip")) + sorted(_CSRC.glob("*.h")) + [_ROOT / "include" / "breedhip.h"]
 
 BH_OK = 0
 BH_ERR_BAD_ARG = -1
@@ -47,22 +51,31 @@ class BreedHipError(RuntimeError):
         self.code = code
 
 
-def build_native(force: bool = False, verbose: bool = False) -> Path:
-    """Compile libbreedhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+def build_native(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    """Compile libbreedhip.so for gfx950 with hipcc (cross-compiles without a GPU): the translation units in
+    parallel, then one link."""
     if not force and LIB_PATH.exists():
-        newest = max(p.stat().st_mtime for p in _SOURCES)
+        newest = max(p.stat().st_mtime for p in _sources())
         if LIB_PATH.stat().st_mtime >= newest:
             return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libbreedhip.so")
-    cmd = [
-        hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall",
-        f"-I{_ROOT / 'include'}", "-o", str(LIB_PATH), str(_PKG / "csrc" / "breedhip.hip"),
-    ]
+    _BUILD.mkdir(exist_ok=True)
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", f"-I{_ROOT / 'include'}", *extra_flags]
+    jobs = []
+    for u in _UNITS:
+        cmd = [hipcc, *flags, "-c", str(_CSRC / f"{u}.hip"), "-o", str(_BUILD / f"{u}.o")]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((u, subprocess.Popen(cmd)))
+    failed = [u for u, j in jobs if j.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)] + [str(_BUILD / f"{u}.o") for u in _UNITS]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return LIB_PATH
 
 

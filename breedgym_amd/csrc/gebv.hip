@@ -1,0 +1,156 @@
+// libbreedhip.so -- GEBV on the matrix cores (gebv_mfma.h: byte-layout rows; gebv_bits.h: bit planes) and the
+// selection indices (bh_optimal_haploid).
+#include "ctx.h"
+#include "gebv_bits.h"
+#include "gebv_mfma.h"
+#include "index_kernels.h"
+
+using namespace bhh;
+
+namespace bhh {
+
+// GEBV of rows already in memory on the matrix cores (gebv_mfma.h), all traits
+int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
+  constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
+  const int64_t n_tiles = (rows + 31) / 32, rows_pad = n_tiles * 32;
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((8192 + n_tiles - 1) / n_tiles, c->n_chunks / 6));
+  const int64_t per_slice = (c->n_chunks + slices - 1) / slices;
+  slices = (c->n_chunks + per_slice - 1) / per_slice;
+  const int64_t need = slices * rows_pad * bh::kGebvCols;
+  if (need > c->partial_cap) {
+    BH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_partial) BH_HIP(hipFree(c->d_partial));
+    c->d_partial = nullptr;
+    c->partial_cap = 0;
+    BH_HIP(hipMalloc(&c->d_partial, (size_t)need * sizeof(int32_t)));
+    c->partial_cap = need;
+  }
+  for (size_t g = 0; g < c->d_Bpack.size(); ++g) {
+    const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
+    bh::GebvMfmaParams p{};
+    p.pop = d_pop;
+    p.B = static_cast<const bh::i32x4 *>(c->d_Bpack[g]);
+    p.partial = c->d_partial;
+    p.pitch = c->pitch;
+    p.rows = (int32_t)rows;
+    p.rows_pad = (int32_t)rows_pad;
+    p.n_chunks = c->n_chunks;
+    p.chunks_per_slice = (int32_t)per_slice;
+    hipLaunchKernelGGL(bh::gebv_mfma_kernel, dim3((unsigned)((n_tiles + 3) / 4), (unsigned)slices), dim3(256), 0,
+                       c->stream, p);
+    BH_HIP(hipGetLastError());
+    bh::GebvFinishParams f{};
+    f.partial = c->d_partial;
+    f.scale = c->d_scale + t0;
+    f.gebv = d_gebv;
+    f.rows = (int32_t)rows;
+    f.rows_pad = (int32_t)rows_pad;
+    f.slices = (int32_t)slices;
+    f.T = (int32_t)tn;
+    f.Tstride = (int32_t)c->T;
+    f.t0 = (int32_t)t0;
+    f.cols = bh::kGebvCols;
+    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+// GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
+// source row of every output row.
+#ifndef BH_GEBV_BITS_WGS  // tuning experiments only: workgroups the K slicing aims at
+#define BH_GEBV_BITS_WGS 512
+#endif
+int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
+  constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
+#ifndef BH_GEBV_BITS_F  // tuning experiments only: 32-row tiles per wave
+#define BH_GEBV_BITS_F 1
+#endif
+  constexpr int F = BH_GEBV_BITS_F;
+  const int64_t row_groups = (rows + 128 * F - 1) / (128 * F), rows_pad = row_groups * 128 * F;
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((BH_GEBV_BITS_WGS + row_groups - 1) / row_groups, c->n_mc));
+  const int64_t per_slice = (c->n_mc + slices - 1) / slices;
+  slices = (c->n_mc + per_slice - 1) / per_slice;
+  const int64_t need = slices * rows_pad * bh::kGebvCols;
+  if (need > c->partial_cap) {
+    BH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_partial) BH_HIP(hipFree(c->d_partial));
+    c->d_partial = nullptr;
+    c->partial_cap = 0;
+    BH_HIP(hipMalloc(&c->d_partial, (size_t)need * sizeof(int32_t)));
+    c->partial_cap = need;
+  }
+  for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
+    const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
+    const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;
+    bh::GebvBitsParams p{};
+    p.rows = reinterpret_cast<const uint8_t *>(d_rows);
+    p.idx = d_idx;
+    p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
+    p.partial = c->d_partial;
+    p.row_bytes = (int64_t)16 * c->nw;
+    p.n_src = (int32_t)n_src;
+    p.n_rows = (int32_t)rows;
+    p.rows_pad = (int32_t)rows_pad;
+    p.n_mc = c->n_mc;
+    p.mc_per_slice = (int32_t)per_slice;
+    const dim3 grid((unsigned)row_groups, (unsigned)slices);
+    if (nt == 1)
+      hipLaunchKernelGGL((bh::gebv_bits_kernel<1, F>), grid, dim3(256), 0, c->stream, p);
+    else
+      hipLaunchKernelGGL((bh::gebv_bits_kernel<2, F>), grid, dim3(256), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+    bh::GebvFinishParams f{};
+    f.partial = c->d_partial;
+    f.scale = c->d_scale + t0;
+    f.gebv = d_gebv;
+    f.rows = (int32_t)rows;
+    f.rows_pad = (int32_t)rows_pad;
+    f.slices = (int32_t)slices;
+    f.T = (int32_t)tn;
+    f.Tstride = (int32_t)c->T;
+    f.t0 = (int32_t)t0;
+    f.cols = 32 * nt;
+    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+}  // namespace bhh
+
+extern "C" {
+
+int bh_optimal_haploid(bh_ctx *c, const uint8_t *d_pop, int64_t n_rows, const int32_t *d_block_start,
+                       int64_t n_blocks, uint8_t *d_ohp, float *d_ohv) {
+  if (int rc = check_ctx(c)) return rc;
+  if (n_rows < 0 || n_blocks < 0) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: negative size");
+  if (n_rows == 0) return BH_OK;
+  if (!d_pop || (!d_ohp && !d_ohv)) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: null device pointer");
+  if (n_blocks > 0 && !d_block_start) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: blocks without offsets");
+  if (c->T == 0) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: the context has no traits");
+  if (n_rows > 0x3FFFFFFF || n_blocks > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_optimal_haploid: too large");
+  for (int t0 = 0; t0 < c->T; t0 += bh::kOhvTraits) {
+    bh::OhvParams p{};
+    p.pop = d_pop;
+    p.eff = c->d_eff;
+    p.effsum = c->d_effsum;
+    p.block_start = d_block_start;
+    p.ohp = d_ohp;
+    p.ohv = d_ohv;
+    p.pitch = c->pitch;
+    p.effPitch = c->effPitch;
+    p.M = (int32_t)c->M;
+    p.T = (int32_t)c->T;
+    p.t0 = t0;
+    p.tcount = (int32_t)std::min<int64_t>(bh::kOhvTraits, c->T - t0);
+    p.n_rows = (int32_t)n_rows;
+    p.n_blocks = (int32_t)n_blocks;
+    hipLaunchKernelGGL(bh::optimal_haploid_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+    if (!d_ohv) break;  // the haploid itself is complete after the first launch
+  }
+  return BH_OK;
+}
+
+}  // extern "C"

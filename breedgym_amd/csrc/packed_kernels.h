@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "founders.h"
 #include "mask_stream.h"
 #include "row_kernels.h"
 

@@ -512,11 +512,6 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   }
 }
 
-__device__ __forceinline__ uint32_t orderable(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-
 // offspring dword k of one 16-byte vector: dword k holds markers 2k, 2k+1 as bytes
 // [m0 a0, m0 a1, m1 a0, m1 a1]; output byte (marker, p) = parent p's byte (marker, mask_p).
 // zz = the vector's 16 mask bits, bit i for output byte i.  The multiply drops bits 4k .. 4k+3 onto
@@ -948,127 +943,4 @@ __global__ __launch_bounds__(256) void reward_max_kernel(const float *g, int64_t
   __syncthreads();
   if (tid == 0) out[e * pitch] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
-
-// ---- top-k by bitonic sort in LDS --------------------------------------------------------
-// key = (~orderable(score)) << 32 | index : ascending key order = descending score, ties to
-// the lower index (jax.lax.top_k).  One block sorts one chunk of up to P (power of two)
-// candidates of one row and emits its first kk (index, score) pairs.
-struct TopkParams {
-  const float *scores;    // (rows, n_in) candidate scores
-  const int32_t *in_idx;  // (rows, n_in) original indices, or null (= position)
-  int32_t *out_idx;       // (rows, chunks*kk)
-  float *out_scores;      // (rows, chunks*kk) or null
-  int32_t n_in, chunk, P, kk;
-};
-
-__global__ __launch_bounds__(1024) void topk_chunk_kernel(const TopkParams p) {
-  extern __shared__ __align__(16) uint64_t keys[];
-  const int row = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int base = ch * p.chunk;
-  const int cnt = min(p.chunk, p.n_in - base);
-  const float *sc = p.scores + (int64_t)row * p.n_in + base;
-  const int32_t *ii = p.in_idx ? p.in_idx + (int64_t)row * p.n_in + base : nullptr;
-  for (int j = tid; j < p.P; j += nt) {
-    uint64_t k = ~0ull;
-    if (j < cnt) {
-      const uint32_t id = ii ? (uint32_t)ii[j] : (uint32_t)(base + j);
-      k = ((uint64_t)(~orderable(sc[j])) << 32) | id;
-    }
-    keys[j] = k;
-  }
-  __syncthreads();
-  for (int size = 2; size <= p.P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int j = tid; j < (p.P >> 1); j += nt) {
-        const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const uint64_t a = keys[lo], b = keys[hi];
-        if ((a > b) == up) {
-          keys[lo] = b;
-          keys[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  const int n_chunks = gridDim.x;
-  for (int j = tid; j < p.kk; j += nt) {
-    const uint64_t k = keys[j];
-    const int64_t o = (int64_t)row * n_chunks * p.kk + (int64_t)ch * p.kk + j;
-    const bool valid = j < cnt;
-    p.out_idx[o] = valid ? (int32_t)(uint32_t)k : -1;
-    if (p.out_scores) {
-      // undo the key: orderable -> float
-      uint32_t u = ~(uint32_t)(k >> 32);
-      u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
-      p.out_scores[o] = valid ? __uint_as_float(u) : -INFINITY;
-    }
-  }
-}
-
-// ---- founder draw of VecBreedGym.reset on the device ---------------------------------------
-// env e: key_e = split(env_key, E+1)[1+e]; permutation(key_e, N)[:n] by jax's `_shuffle`:
-// `rounds` times { key, sub = split(key); stable-sort the current order by random_bits(sub, N) }.
-// One workgroup per env; the sort is a bitonic sort of (random word << 32 | position) in LDS,
-// which is the stable sort because positions are unique.  N <= 8192.
-struct FoundersParams {
-  int32_t *out;  // (E, n)
-  uint32_t key0, key1;
-  int32_t E, N, n, P, rounds;
-  int32_t layout;  // LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE
-  int32_t E_total, env_offset;  // env e here is env env_offset + e of E_total (bh_set_env_window)
-};
-
-// the draw of env e by one workgroup of any size; fk: 16 P bytes of LDS (P keys, then 2 x P int32 orders)
-__device__ __forceinline__ void founders_role(const FoundersParams &p, const int e, uint64_t *fk) {
-  int32_t *x = reinterpret_cast<int32_t *>(fk + p.P), *y = x + p.P;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E_total + 1), (uint32_t)(1 + p.env_offset + e), p.layout);
-  for (int i = tid; i < p.N; i += nt) x[i] = i;
-  const int L = p.N + (p.N & 1), h = L >> 1;
-  for (int rd = 0; rd < p.rounds; ++rd) {
-    const u32x2 nk = split_at(k.x, k.y, 2u, 0u, p.layout), sub = split_at(k.x, k.y, 2u, 1u, p.layout);
-    k = nk;
-    if (p.layout == LAYOUT_PARTITIONABLE) {
-      for (int i = tid; i < p.N; i += nt)
-        fk[i] = ((uint64_t)bits_word_partitionable(sub.x, sub.y, (uint32_t)i) << 32) | (uint32_t)i;
-    } else {
-      for (int i = tid; i < h; i += nt) {  // random_bits(sub, N): odd N is padded with a 0 counter
-        const bool second = i + h < p.N;
-        const u32x2 o = threefry2x32(sub.x, sub.y, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
-        fk[i] = ((uint64_t)o.x << 32) | (uint32_t)i;
-        if (second) fk[i + h] = ((uint64_t)o.y << 32) | (uint32_t)(i + h);
-      }
-    }
-    for (int i = p.N + tid; i < p.P; i += nt) fk[i] = ~0ull;
-    __syncthreads();
-    for (int size = 2; size <= p.P; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int j = tid; j < (p.P >> 1); j += nt) {
-          const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1)), hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          const uint64_t a = fk[lo], b = fk[hi];
-          if ((a > b) == up) {
-            fk[lo] = b;
-            fk[hi] = a;
-          }
-        }
-        __syncthreads();
-      }
-    }
-    for (int i = tid; i < p.N; i += nt) y[i] = x[(uint32_t)fk[i]];
-    __syncthreads();
-    int32_t *t = x;
-    x = y;
-    y = t;
-  }
-  for (int i = tid; i < p.n; i += nt) p.out[(int64_t)e * p.n + i] = x[i];
-}
-
-__global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
-  extern __shared__ __align__(16) uint64_t fk_lds[];
-  founders_role(p, (int)blockIdx.x, fk_lds);
-}
-
 }  // namespace bh

@@ -1,0 +1,406 @@
+// libbreedhip.so -- ranking and draws: bh_topk, bh_selection_actions, bh_founders_device / _deferred.
+//
+// Which route a call takes:
+//   bh_topk               n <= 16384: bitonic sort in LDS (topk_chunk_kernel);  n > 16384, k <= 16384: radix select
+//                         + sort of the winners (topk_select_kernel);  k > 16384: radix sort in HBM (sort_kernels.h)
+//   bh_founders_device    germplasm <= 8192: one workgroup per env in LDS (founders.h; <= 1024 rows may ride on the
+//                         horizon launch);  above: JAX's shuffle rounds as radix sorts in HBM, envs side by side
+//   bh_selection_actions  n <= 8192 and k(k-1)/2 <= 8192: one workgroup per env in LDS (selection_actions_kernel);
+//                         above: bh_topk's routes for the k best, radix-sort shuffle of the pair ranks, un-ranking
+#include "ctx.h"
+#include "select_kernels.h"
+#include "sort_kernels.h"
+
+using namespace bhh;
+
+namespace {
+
+constexpr int kTopkChunk = 16384;  // candidates one block sorts in LDS (128 KiB of keys)
+
+int launch_founders(bh_ctx *c, const bh::FoundersParams &p) {
+  const size_t lds = (size_t)p.P * 16;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::founders_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(founders LDS): %s", hipGetErrorString(e));
+  }
+  const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, p.P / 2));
+  hipLaunchKernelGGL(bh::founders_kernel, dim3((unsigned)p.E), dim3(threads), lds, c->stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "founders_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
+
+// ---- the radix sort in HBM (sort_kernels.h) -----------------------------------------------------------------
+struct SortBufs {
+  uint32_t *kA, *kB;
+  int32_t *vA, *vB;
+  uint32_t *hist, *tot, *sub;
+  int64_t stride;  // elements per segment in the four arrays
+  int32_t nb;      // tiles per segment
+};
+
+// segments one batch sorts side by side: <= 2^25 elements of scratch (0.5 GB), <= 65535 (grid.y)
+int64_t sort_batch(int64_t segs, int64_t N) {
+  const int64_t stride = round_up(N, 64);
+  return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(segs, 65535), ((int64_t)1 << 25) / stride));
+}
+
+int sort_layout(bh_ctx *c, int64_t segs, int64_t N, int64_t rounds, SortBufs *b) {
+  b->stride = round_up(N, 64);
+  b->nb = (int32_t)((N + bh::kSortTile - 1) / bh::kSortTile);
+  const int64_t arr = segs * b->stride * 4, hist = segs * 256 * b->nb * 4, tot = segs * 256 * 4,
+                sub = round_up(segs * std::max<int64_t>(rounds, 1) * 8, 256);
+  void *base = c->d_sort;
+  if (int rc = ensure_scratch(c, &base, &c->sort_cap, 4 * arr + hist + tot + sub)) {
+    c->d_sort = base;
+    return rc;
+  }
+  c->d_sort = base;
+  char *q = static_cast<char *>(base);
+  b->kA = reinterpret_cast<uint32_t *>(q);
+  b->kB = reinterpret_cast<uint32_t *>(q + arr);
+  b->vA = reinterpret_cast<int32_t *>(q + 2 * arr);
+  b->vB = reinterpret_cast<int32_t *>(q + 3 * arr);
+  b->hist = reinterpret_cast<uint32_t *>(q + 4 * arr);
+  b->tot = reinterpret_cast<uint32_t *>(q + 4 * arr + hist);
+  b->sub = reinterpret_cast<uint32_t *>(q + 4 * arr + hist + tot);
+  return BH_OK;
+}
+
+// (kA, vA) of every segment sorted by key, stable, back into (kA, vA)
+int radix_sort(bh_ctx *c, const SortBufs &b, int64_t segs, int64_t N) {
+  bh::SortParams p{};
+  p.hist = b.hist;
+  p.bin_total = b.tot;
+  p.seg_stride = b.stride;
+  p.N = (int32_t)N;
+  p.nb = b.nb;
+  for (int pass = 0; pass < 4; ++pass) {
+    const bool fwd = (pass & 1) == 0;
+    p.keys_in = fwd ? b.kA : b.kB;
+    p.vals_in = fwd ? b.vA : b.vB;
+    p.keys_out = fwd ? b.kB : b.kA;
+    p.vals_out = fwd ? b.vB : b.vA;
+    p.shift = 8 * pass;
+    const dim3 tiles((unsigned)b.nb, (unsigned)segs);
+    hipLaunchKernelGGL(bh::sort_hist_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
+    hipLaunchKernelGGL(bh::sort_scan_kernel, dim3(256, (unsigned)segs), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(bh::sort_scatter_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+int shuffle_rounds_for(int64_t n) {  // jax/_src/random.py `_shuffle`
+  return (int)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n)) / std::log(4294967295.0));
+}
+
+// jax.random.permutation(key_e, N) for envs [env_first, env_first + segs) of E_total, key_e = split(env_key,
+// E_total + 1)[1 + e], side by side into b.vA (segment stride b.stride)
+int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int64_t env_first, int64_t segs, int64_t N,
+                     int rounds, const SortBufs &b) {
+  bh::ShuffleKeyParams kp{};
+  kp.subkeys = b.sub;
+  kp.key0 = env_key[0];
+  kp.key1 = env_key[1];
+  kp.segs = (int32_t)segs;
+  kp.rounds = rounds;
+  kp.layout = c->layout;
+  kp.E_total = (int32_t)E_total;
+  kp.env_first = (int32_t)env_first;
+  if (rounds > 0) {
+    hipLaunchKernelGGL(bh::shuffle_subkeys_kernel, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, c->stream, kp);
+    BH_HIP(hipGetLastError());
+  }
+  bh::ShuffleGenParams gp{};
+  gp.subkeys = b.sub;
+  gp.keys = b.kA;
+  gp.vals = b.vA;
+  gp.seg_stride = b.stride;
+  gp.N = (int32_t)N;
+  gp.rounds = rounds;
+  gp.layout = c->layout;
+  const int64_t per_seg = c->layout == bh::LAYOUT_PARTITIONABLE ? N : (N + 1) / 2;
+  const dim3 grid((unsigned)((per_seg + 255) / 256), (unsigned)segs);
+  for (int rd = 0; rd < std::max(rounds, 1); ++rd) {  // N = 1: no round, the identity
+    gp.round = rd;
+    gp.init = rd == 0;
+    hipLaunchKernelGGL(bh::shuffle_gen_kernel, grid, dim3(256), 0, c->stream, gp);
+    BH_HIP(hipGetLastError());
+    if (rounds == 0) break;
+    if (int rc = radix_sort(c, b, segs, N)) return rc;
+  }
+  return BH_OK;
+}
+
+
+int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t k, int32_t *d_idx_out) {
+  if (n_rows < 0 || n < 0 || k < 0 || k > n) return fail(BH_ERR_BAD_ARG, "bh_topk: need 0 <= k <= n");
+  if (n_rows == 0 || k == 0) return BH_OK;
+  if (!d_scores || !d_idx_out) return fail(BH_ERR_BAD_ARG, "bh_topk: null device pointer");
+  if (n > 0x7FFFFFFF || n_rows > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_topk: shape too large");
+  if (k > kTopkChunk) {
+    // more winners than one workgroup sorts in LDS: the whole row through the radix sort in HBM, ascending
+    // ~orderable(score) (stable: ties to the lower index), and its first k
+    for (int64_t r0 = 0; r0 < n_rows;) {
+      const int64_t segs = std::min(sort_batch(n_rows, n), n_rows - r0);
+      SortBufs b{};
+      if (int rc = sort_layout(c, segs, n, 0, &b)) return rc;
+      bh::ScoreKeyParams sp{};
+      sp.scores = d_scores + r0 * n;
+      sp.keys = b.kA;
+      sp.vals = b.vA;
+      sp.seg_stride = b.stride;
+      sp.N = (int32_t)n;
+      hipLaunchKernelGGL(bh::score_keys_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
+                         c->stream, sp);
+      BH_HIP(hipGetLastError());
+      if (int rc = radix_sort(c, b, segs, n)) return rc;
+      hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)segs), dim3(256), 0,
+                         c->stream, b.vA, b.stride, (int32_t)k, d_idx_out + r0 * k);
+      BH_HIP(hipGetLastError());
+      r0 += segs;
+    }
+    return BH_OK;
+  }
+
+  if (!c->big_lds_set) {
+    BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::topk_chunk_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
+    c->big_lds_set = true;
+  }
+  if (n > kTopkChunk) {
+    // long vectors: radix select of the k-th key, then sort only the k winners in LDS
+    bh::TopkSelectParams q{};
+    q.scores = d_scores;
+    q.out_idx = d_idx_out;
+    q.n = (int32_t)n;
+    q.k = (int32_t)k;
+    q.P = 2;
+    while (q.P < k) q.P <<= 1;
+    const size_t lds = (size_t)q.P * 8;
+    if (lds > 48 * 1024 && !c->select_lds_set) {
+      BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::topk_select_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
+      c->select_lds_set = true;
+    }
+    hipLaunchKernelGGL(bh::topk_select_kernel, dim3((unsigned)n_rows), dim3(1024), lds, c->stream, q);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+  }
+  // level 0 reads the caller's scores; every level keeps the best kk of each chunk of <= 16384
+  // candidates, until one chunk is left.  top-k of a union = top-k of the parts' top-k.
+  const float *in_s = d_scores;
+  const int32_t *in_i = nullptr;
+  int64_t n_in = n;
+  int flip = 0;
+  for (;;) {
+    const int64_t chunks = (n_in + kTopkChunk - 1) / kTopkChunk;
+    const int64_t chunk = chunks == 1 ? n_in : kTopkChunk;
+    const int64_t kk = std::min<int64_t>(k, chunk);
+    int64_t P = 2;
+    while (P < chunk) P <<= 1;
+    bh::TopkParams p{};
+    p.scores = in_s;
+    p.in_idx = in_i;
+    p.n_in = (int32_t)n_in;
+    p.chunk = (int32_t)chunk;
+    p.P = (int32_t)P;
+    p.kk = (int32_t)kk;
+    if (chunks == 1) {
+      p.out_idx = d_idx_out;
+      p.out_scores = nullptr;
+    } else {
+      const int64_t need = n_rows * chunks * kk;
+      if (need > c->cand_cap) {
+        for (int i = 0; i < 2; ++i) {
+          if (c->d_cand_s[i]) (void)hipFree(c->d_cand_s[i]);
+          if (c->d_cand_i[i]) (void)hipFree(c->d_cand_i[i]);
+          c->d_cand_s[i] = nullptr;
+          c->d_cand_i[i] = nullptr;
+        }
+        c->cand_cap = 0;
+        for (int i = 0; i < 2; ++i) {
+          BH_HIP(hipMalloc(&c->d_cand_s[i], need * sizeof(float)));
+          BH_HIP(hipMalloc(&c->d_cand_i[i], need * sizeof(int32_t)));
+        }
+        c->cand_cap = need;
+      }
+      p.out_idx = c->d_cand_i[flip];
+      p.out_scores = c->d_cand_s[flip];
+    }
+    const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, P / 2));
+    hipLaunchKernelGGL(bh::topk_chunk_kernel, dim3((unsigned)chunks, (unsigned)n_rows), dim3(threads),
+                       (size_t)P * 8, c->stream, p);
+    BH_HIP(hipGetLastError());
+    if (chunks == 1) break;
+    in_s = c->d_cand_s[flip];
+    in_i = c->d_cand_i[flip];
+    n_in = chunks * kk;
+    flip ^= 1;
+  }
+  return BH_OK;
+}
+
+
+}  // namespace
+
+namespace bhh {
+
+// a deferred founder draw that found no launch to ride on is made now, in stream order
+int flush_founders(bh_ctx *c) {
+  if (!c->founders_pending) return BH_OK;
+  c->founders_pending = false;
+  return launch_founders(c, c->fp_pending);
+}
+
+}  // namespace bhh
+
+extern "C" {
+
+int bh_topk(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t k, int32_t *d_idx_out) {
+  if (int rc = check_ctx(c)) return rc;
+  return topk_impl(c, d_scores, n_rows, n, k, d_idx_out);
+}
+
+int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n, int64_t k, int64_t n_crosses,
+                         uint32_t env_key[2], int32_t *d_actions) {
+  if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
+  if (!env_key || n_envs < 0 || n <= 0) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: bad sizes");
+  const int64_t n_pairs = k * (k - 1) / 2;
+  if (k < 2 || k > n) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 2 <= k <= n");
+  if (n_crosses < 1 || n_crosses > n_pairs || n_crosses > n)
+    return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 1 <= n_crosses <= min(k(k-1)/2, n)");
+  if (n > 0x3FFFFFFF || n_pairs > 0x7FFFFFFF || n_envs > 65535)
+    return fail(BH_ERR_UNSUPPORTED, "bh_selection_actions: n <= 2^30, k(k-1)/2 < 2^31 and n_envs <= 65535");
+  const bool in_lds = n <= 8192 && n_pairs <= 8192;  // one workgroup per env keeps everything in LDS
+  const int64_t e_total = c->envs_total > 0 ? c->envs_total : n_envs, e_off = c->envs_total > 0 ? c->env_offset : 0;
+  if (e_off + n_envs > e_total) return fail(BH_ERR_BAD_ARG, "more envs than the env window holds");
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(e_total + 1), 0u, c->layout);
+  if (n_envs > 0) {
+    if (!d_scores || !d_actions) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: null device pointer");
+    if (in_lds) {
+      bh::SelectionParams p{};
+      p.scores = d_scores;
+      p.actions = d_actions;
+      p.key0 = env_key[0];
+      p.key1 = env_key[1];
+      p.E = (int32_t)n_envs;
+      p.n = (int32_t)n;
+      p.k = (int32_t)k;
+      p.n_crosses = (int32_t)n_crosses;
+      p.n_offspring = (int32_t)((n + n_crosses - 1) / n_crosses);
+      p.n_pairs = (int32_t)n_pairs;
+      p.P_top = 2;
+      while (p.P_top < n) p.P_top <<= 1;
+      p.P_pairs = 2;
+      while (p.P_pairs < n_pairs) p.P_pairs <<= 1;
+      p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_pairs)) / std::log(4294967295.0));
+      p.layout = c->layout;
+      p.E_total = (int32_t)e_total;
+      p.env_offset = (int32_t)e_off;
+      const int PK = std::max(p.P_top, p.P_pairs);
+      const size_t lds = (size_t)PK * 8 + (size_t)p.P_pairs * 8 + (size_t)k * 4;
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::selection_actions_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(selection LDS): %s", hipGetErrorString(e));
+      }
+      const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, PK / 2));
+      hipLaunchKernelGGL(bh::selection_actions_kernel, dim3((unsigned)n_envs), dim3(threads), lds, c->stream, p);
+      BH_HIP(hipGetLastError());
+    } else {
+      // the k best of every env (bh_topk's routes), then per batch of envs: the shuffle of the pair ranks as
+      // radix sorts in HBM and the un-ranking of its first n_crosses
+      void *best = c->d_best;
+      const int rc0 = ensure_scratch(c, &best, &c->best_cap, n_envs * k * 4);
+      c->d_best = best;
+      if (rc0) return rc0;
+      if (int rc = topk_impl(c, d_scores, n_envs, n, k, static_cast<int32_t *>(best))) return rc;
+      const int rounds = shuffle_rounds_for(n_pairs);
+      for (int64_t e0 = 0; e0 < n_envs;) {
+        const int64_t segs = std::min(sort_batch(n_envs, n_pairs), n_envs - e0);
+        SortBufs b{};
+        if (int rc = sort_layout(c, segs, n_pairs, rounds, &b)) return rc;
+        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_pairs, rounds, b)) return rc;
+        bh::PairActionParams q{};
+        q.perm = b.vA;
+        q.best = static_cast<const int32_t *>(best) + e0 * k;
+        q.actions = d_actions + e0 * n * 2;
+        q.seg_stride = b.stride;
+        q.n = (int32_t)n;
+        q.k = (int32_t)k;
+        q.n_offspring = (int32_t)((n + n_crosses - 1) / n_crosses);
+        hipLaunchKernelGGL(bh::pair_actions_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
+                           c->stream, q);
+        BH_HIP(hipGetLastError());
+        e0 += segs;
+      }
+    }
+  }
+  env_key[0] = nk.x;
+  env_key[1] = nk.y;
+  return BH_OK;
+}
+
+static int founders_device_impl(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                                int32_t *d_out, bool defer) {
+  if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
+  if (!env_key || n_envs < 0 || n < 0 || n > n_germplasm || (n_envs * n > 0 && !d_out))
+    return fail(BH_ERR_BAD_ARG, "bh_founders_device: need 0 <= n <= n_germplasm");
+  if (n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: too many envs");
+  const int64_t e_total = c->envs_total > 0 ? c->envs_total : n_envs, e_off = c->envs_total > 0 ? c->env_offset : 0;
+  if (e_off + n_envs > e_total) return fail(BH_ERR_BAD_ARG, "more envs than the env window holds");
+  const bh::u32x2 nk = bh::split_at(env_key[0], env_key[1], (uint32_t)(e_total + 1), 0u, c->layout);
+  if (n_envs * n > 0) {
+    if (n_germplasm > 8192) {
+      // beyond one workgroup's LDS: the shuffle rounds as radix sorts in HBM, envs side by side (sort_kernels.h)
+      if (n_germplasm > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: germplasm too large");
+      const int rounds = shuffle_rounds_for(n_germplasm);
+      for (int64_t e0 = 0; e0 < n_envs;) {
+        const int64_t segs = std::min(sort_batch(n_envs, n_germplasm), n_envs - e0);
+        SortBufs b{};
+        if (int rc = sort_layout(c, segs, n_germplasm, rounds, &b)) return rc;
+        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_germplasm, rounds, b)) return rc;
+        hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
+                           c->stream, b.vA, b.stride, (int32_t)n, d_out + e0 * n);
+        BH_HIP(hipGetLastError());
+        e0 += segs;
+      }
+    } else {
+      bh::FoundersParams p{};
+      p.out = d_out;
+      p.key0 = env_key[0];
+      p.key1 = env_key[1];
+      p.E = (int32_t)n_envs;
+      p.N = (int32_t)n_germplasm;
+      p.n = (int32_t)n;
+      p.P = 2;
+      while (p.P < n_germplasm) p.P <<= 1;
+      p.rounds = (int32_t)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n_germplasm)) / std::log(4294967295.0));
+      p.layout = c->layout;
+      p.E_total = (int32_t)e_total;
+      p.env_offset = (int32_t)e_off;
+      if (int rc = (defer ? (c->fp_pending = p, c->founders_pending = true, BH_OK) : launch_founders(c, p))) return rc;
+    }
+  }
+  env_key[0] = nk.x;
+  env_key[1] = nk.y;
+  return BH_OK;
+}
+
+int bh_founders_device(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                       int32_t *d_out) {
+  return founders_device_impl(c, env_key, n_envs, n_germplasm, n, d_out, false);
+}
+
+int bh_founders_deferred(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n,
+                         int32_t *d_out) {
+  return founders_device_impl(c, env_key, n_envs, n_germplasm, n, d_out, true);
+}
+
+}  // extern "C"

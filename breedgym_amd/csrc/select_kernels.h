@@ -12,9 +12,78 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "row_kernels.h"
+#include "founders.h"
+#include "threefry.h"
 
 namespace bh {
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// ---- top-k by bitonic sort in LDS --------------------------------------------------------
+// key = (~orderable(score)) << 32 | index : ascending key order = descending score, ties to
+// the lower index (jax.lax.top_k).  One block sorts one chunk of up to P (power of two)
+// candidates of one row and emits its first kk (index, score) pairs.
+struct TopkParams {
+  const float *scores;    // (rows, n_in) candidate scores
+  const int32_t *in_idx;  // (rows, n_in) original indices, or null (= position)
+  int32_t *out_idx;       // (rows, chunks*kk)
+  float *out_scores;      // (rows, chunks*kk) or null
+  int32_t n_in, chunk, P, kk;
+};
+
+__global__ __launch_bounds__(1024) void topk_chunk_kernel(const TopkParams p) {
+  extern __shared__ __align__(16) uint64_t keys[];
+  const int row = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int base = ch * p.chunk;
+  const int cnt = min(p.chunk, p.n_in - base);
+  const float *sc = p.scores + (int64_t)row * p.n_in + base;
+  const int32_t *ii = p.in_idx ? p.in_idx + (int64_t)row * p.n_in + base : nullptr;
+  for (int j = tid; j < p.P; j += nt) {
+    uint64_t k = ~0ull;
+    if (j < cnt) {
+      const uint32_t id = ii ? (uint32_t)ii[j] : (uint32_t)(base + j);
+      k = ((uint64_t)(~orderable(sc[j])) << 32) | id;
+    }
+    keys[j] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= p.P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int j = tid; j < (p.P >> 1); j += nt) {
+        const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int n_chunks = gridDim.x;
+  for (int j = tid; j < p.kk; j += nt) {
+    const uint64_t k = keys[j];
+    const int64_t o = (int64_t)row * n_chunks * p.kk + (int64_t)ch * p.kk + j;
+    const bool valid = j < cnt;
+    p.out_idx[o] = valid ? (int32_t)(uint32_t)k : -1;
+    if (p.out_scores) {
+      // undo the key: orderable -> float
+      uint32_t u = ~(uint32_t)(k >> 32);
+      u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+      p.out_scores[o] = valid ? __uint_as_float(u) : -INFINITY;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
+  extern __shared__ __align__(16) uint64_t fk_lds[];
+  founders_role(p, (int)blockIdx.x, fk_lds);
+}
 
 // ascending bitonic sort of P (power of two) 64-bit keys in LDS by the whole workgroup
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, int P) {

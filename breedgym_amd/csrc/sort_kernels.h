@@ -1,0 +1,289 @@
+// Stable key-value sort in HBM over many workgroups: what JAX's sort-based shuffle needs once a draw no longer
+// fits one workgroup's LDS.
+//
+// jax.random.permutation / choice(replace=False) (jax/_src/random.py `_shuffle`) = `rounds` times
+//     key, sub = split(key);  x = stable_sort_by_key(random_bits(sub, 32, N), x)
+// which the reference reaches through `_random_selection` (breedgym/vector/vec_env.py:22-27: the founder draw of
+// every env at reset) and `SelectionScores._convert_actions` (breedgym/vector/vec_wrappers.py:61-79: the random
+// subset of the k(k-1)/2 diallel pairs).  Small draws stay inside LDS (founders.h, select_kernels.h); here the
+// same rounds run as an LSD radix sort on the 32-bit Threefry word -- four passes of 8 bits, each
+//     sort_hist_kernel     per tile and digit value: how many of the tile's keys carry it
+//     sort_scan_kernel     per digit value: exclusive prefix over the tiles, and the value's total
+//     sort_scatter_kernel  every element to  base(value) + prefix(value, tile) + its rank among the tile's
+//                          elements of the same value, in index order
+// so equal words keep their order: the position is the tiebreak, as in the LDS kernels' (word << 32 | position).
+// Segments (envs) are sorted side by side: blockIdx.y is the segment.  HBM-bound: a pass reads 12 and writes
+// 8 bytes per element.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "threefry.h"
+
+namespace bh {
+
+constexpr int kSortThreads = 512;                      // 8 waves
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortItems = 16;                         // elements per lane
+constexpr int kSortTile = kSortThreads * kSortItems;   // 8192 elements per workgroup and pass
+constexpr int kSortWaveSpan = 64 * kSortItems;         // consecutive elements one wave ranks
+
+struct SortParams {
+  const uint32_t *keys_in;
+  const int32_t *vals_in;
+  uint32_t *keys_out;
+  int32_t *vals_out;
+  uint32_t *hist;       // (segs, 256, nb): counts, then exclusive prefixes over the tiles
+  uint32_t *bin_total;  // (segs, 256)
+  int64_t seg_stride;   // elements from one segment to the next in keys / vals
+  int32_t N, nb, shift;
+};
+
+__global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const SortParams p) {
+  __shared__ unsigned cnt[256];
+  const int tid = threadIdx.x, tile = blockIdx.x, seg = blockIdx.y;
+  if (tid < 256) cnt[tid] = 0;
+  __syncthreads();
+  const uint32_t *keys = p.keys_in + (int64_t)seg * p.seg_stride;
+  const int base = tile * kSortTile;
+#pragma unroll 4
+  for (int j = 0; j < kSortItems; ++j) {
+    const int i = base + j * kSortThreads + tid;
+    if (i < p.N) atomicAdd(&cnt[(keys[i] >> p.shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) p.hist[((int64_t)seg * 256 + tid) * p.nb + tile] = cnt[tid];
+}
+
+// inclusive scan over the 256 threads of a workgroup; returns this thread's inclusive value, *total the sum
+__device__ __forceinline__ unsigned scan256(unsigned v, unsigned *wsum, unsigned *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  if (lane == 63) wsum[wv] = v;
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned s = wsum[w];
+    if (w < wv) before += s;
+    all += s;
+  }
+  __syncthreads();
+  *total = all;
+  return v + before;
+}
+
+// one workgroup per (digit value, segment)
+__global__ __launch_bounds__(256) void sort_scan_kernel(const SortParams p) {
+  __shared__ unsigned wsum[4];
+  const int tid = threadIdx.x, d = blockIdx.x, seg = blockIdx.y;
+  uint32_t *h = p.hist + ((int64_t)seg * 256 + d) * p.nb;
+  unsigned carry = 0;
+  for (int t0 = 0; t0 < p.nb; t0 += 256) {
+    const int t = t0 + tid;
+    const unsigned v = t < p.nb ? h[t] : 0u;
+    unsigned total;
+    const unsigned inc = scan256(v, wsum, &total);
+    if (t < p.nb) h[t] = carry + inc - v;
+    carry += total;
+  }
+  if (tid == 0) p.bin_total[seg * 256 + d] = carry;
+}
+
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortParams p) {
+  __shared__ unsigned cnt[kSortWaves][256];  // per wave: running count, then the wave's first slot, per digit value
+  __shared__ unsigned gbase[256];
+  __shared__ unsigned wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, tile = blockIdx.x, seg = blockIdx.y;
+  for (int j = tid; j < kSortWaves * 256; j += kSortThreads) (&cnt[0][0])[j] = 0;
+  // where this tile's elements of every digit value start: all smaller values, then the same value in earlier
+  // tiles.  Threads 0-255 own a digit value each; the other four waves only walk through the barriers.
+  {
+    const unsigned v = tid < 256 ? p.bin_total[seg * 256 + tid] : 0u;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63 && wv < 4) wsum[wv] = inc;
+    __syncthreads();
+    if (tid < 256) {
+      unsigned before = 0;
+      for (int w = 0; w < wv; ++w) before += wsum[w];
+      gbase[tid] = before + inc - v + p.hist[((int64_t)seg * 256 + tid) * p.nb + tile];
+    }
+  }
+  __syncthreads();
+
+  const uint32_t *keys = p.keys_in + (int64_t)seg * p.seg_stride;
+  const int32_t *vals = p.vals_in + (int64_t)seg * p.seg_stride;
+  const int wbase = tile * kSortTile + wv * kSortWaveSpan;
+  uint32_t k[kSortItems];
+  int32_t v[kSortItems];
+  unsigned lr[kSortItems];
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const int i = wbase + j * 64 + lane;
+    const bool valid = i < p.N;
+    k[j] = valid ? keys[i] : 0u;
+    v[j] = valid ? vals[i] : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const int i = wbase + j * 64 + lane;
+    const bool valid = i < p.N;
+    const unsigned d = (k[j] >> p.shift) & 255u;
+    uint64_t peers = __ballot(valid);  // the lanes of this trip that carry the same digit value
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const unsigned rank = (unsigned)__popcll(peers & lt);
+    // LDS operations of one wave are served in issue order: every peer reads the count before the first peer bumps it
+    const unsigned pre = cnt[wv][d];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) cnt[wv][d] = pre + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    lr[j] = pre + rank;
+  }
+  __syncthreads();
+  if (tid < 256) {  // counts -> first slots, wave after wave (= index order)
+    unsigned run = gbase[tid];
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      const unsigned c = cnt[w][tid];
+      cnt[w][tid] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  uint32_t *ko = p.keys_out + (int64_t)seg * p.seg_stride;
+  int32_t *vo = p.vals_out + (int64_t)seg * p.seg_stride;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const int i = wbase + j * 64 + lane;
+    if (i < p.N) {
+      const unsigned dst = cnt[wv][(k[j] >> p.shift) & 255u] + lr[j];
+      ko[dst] = k[j];
+      vo[dst] = v[j];
+    }
+  }
+}
+
+// ---- what is sorted ---------------------------------------------------------------------------------------
+// The shuffle keys of every round of every segment: segment s is env env_offset + seg0 + s of E_total, its key
+// split(env_key, E_total + 1)[1 + env]; round r sorts by random_bits(sub_r) with (key, sub_r) = split(key).
+struct ShuffleKeyParams {
+  uint32_t *subkeys;  // (segs, rounds, 2)
+  uint32_t key0, key1;
+  int32_t segs, rounds, layout;
+  int32_t E_total, env_first;  // env of segment 0
+};
+
+__global__ void shuffle_subkeys_kernel(const ShuffleKeyParams p) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.segs) return;
+  u32x2 k = split_at(p.key0, p.key1, (uint32_t)(p.E_total + 1), (uint32_t)(1 + p.env_first + s), p.layout);
+  for (int rd = 0; rd < p.rounds; ++rd) {
+    const u32x2 nk = split_at(k.x, k.y, 2u, 0u, p.layout), sub = split_at(k.x, k.y, 2u, 1u, p.layout);
+    k = nk;
+    p.subkeys[((int64_t)s * p.rounds + rd) * 2] = sub.x;
+    p.subkeys[((int64_t)s * p.rounds + rd) * 2 + 1] = sub.y;
+  }
+}
+
+struct ShuffleGenParams {
+  const uint32_t *subkeys;  // (segs, rounds, 2)
+  uint32_t *keys;           // (segs, seg_stride): random_bits(sub, N)
+  int32_t *vals;            // (segs, seg_stride): set to 0..N-1 when `init`
+  int64_t seg_stride;
+  int32_t N, rounds, round, layout, init;
+};
+
+// random_bits(sub, N) in either layout (threefry.h): the original one hashes positions (i, i + h) together
+__global__ __launch_bounds__(256) void shuffle_gen_kernel(const ShuffleGenParams p) {
+  const int seg = blockIdx.y;
+  const uint32_t s0 = p.subkeys[((int64_t)seg * p.rounds + p.round) * 2],
+                 s1 = p.subkeys[((int64_t)seg * p.rounds + p.round) * 2 + 1];
+  uint32_t *keys = p.keys + (int64_t)seg * p.seg_stride;
+  int32_t *vals = p.vals + (int64_t)seg * p.seg_stride;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (p.layout == LAYOUT_PARTITIONABLE) {
+    if (i < p.N) {
+      keys[i] = bits_word_partitionable(s0, s1, (uint32_t)i);
+      if (p.init) vals[i] = i;
+    }
+  } else {
+    const int h = (p.N + 1) >> 1;
+    if (i < h) {
+      const bool second = i + h < p.N;  // odd N: the last pair is padded with a 0 counter
+      const u32x2 o = threefry2x32(s0, s1, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
+      keys[i] = o.x;
+      if (p.init) vals[i] = i;
+      if (second) {
+        keys[i + h] = o.y;
+        if (p.init) vals[i + h] = i + h;
+      }
+    }
+  }
+}
+
+// keys for jax.lax.top_k as a sort: ascending ~orderable(score) = descending score, ties to the lower index
+struct ScoreKeyParams {
+  const float *scores;  // (segs, N)
+  uint32_t *keys;
+  int32_t *vals;
+  int64_t seg_stride;
+  int32_t N;
+};
+
+__global__ __launch_bounds__(256) void score_keys_kernel(const ScoreKeyParams p) {
+  const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.N) return;
+  const uint32_t u = __float_as_uint(p.scores[(int64_t)seg * p.N + i]);
+  p.keys[(int64_t)seg * p.seg_stride + i] = ~(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u));
+  p.vals[(int64_t)seg * p.seg_stride + i] = i;
+}
+
+// out[s, 0:take] = vals[s, 0:take]
+__global__ __launch_bounds__(256) void take_front_kernel(const int32_t *vals, int64_t seg_stride, int32_t take,
+                                                         int32_t *out) {
+  const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i < take) out[(int64_t)seg * take + i] = vals[(int64_t)seg * seg_stride + i];
+}
+
+// `SelectionScores._convert_actions`' tail (vec_wrappers.py:66-79) from a shuffled list of pair ranks:
+// slot s of env e takes pair perm[s / n_offspring]; rank t -> (i, j), i < j, row-major upper triangle of k x k.
+struct PairActionParams {
+  const int32_t *perm;  // (segs, seg_stride) shuffled pair ranks (the first n_crosses are read)
+  const int32_t *best;  // (segs, k) top-k indices, best first
+  int32_t *actions;     // (segs, n, 2)
+  int64_t seg_stride;
+  int32_t n, k, n_offspring;
+};
+
+__global__ __launch_bounds__(256) void pair_actions_kernel(const PairActionParams p) {
+  const int seg = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.n) return;
+  const int64_t t = p.perm[(int64_t)seg * p.seg_stride + s / p.n_offspring], k = p.k;
+  // rows before row i hold i (2k - i - 1) / 2 pairs
+  const double b = 2.0 * (double)k - 1.0;
+  int64_t i = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+  i = i < 0 ? 0 : (i > k - 2 ? k - 2 : i);
+  while (i > 0 && i * (2 * k - i - 1) / 2 > t) --i;
+  while ((i + 1) * (2 * k - i - 2) / 2 <= t) ++i;
+  const int64_t j = t - i * (2 * k - i - 1) / 2 + i + 1;
+  const int32_t *best = p.best + (int64_t)seg * p.k;
+  p.actions[((int64_t)seg * p.n + s) * 2] = best[i];
+  p.actions[((int64_t)seg * p.n + s) * 2 + 1] = best[j];
+}
+
+}  // namespace bh

@@ -60,32 +60,20 @@ class SelectionScores(VectorWrapper):
             vec_env = VecBreedGym(**kwargs)
         super().__init__(vec_env)
 
-        if k is None:
-            k = self.individual_per_gen // 10
-        elif k > self.individual_per_gen:
-            raise ValueError(
-                f"Cannot select {k} best from a population of ", f"{self.individual_per_gen} individuals",
-            )
-        self.k = k
-
-        max_crosses = self.k * (self.k - 1) // 2
-        if n_crosses is None:
-            n_crosses = max_crosses
-        elif n_crosses > max_crosses:
-            raise ValueError(
-                "Incompatible value for k and n_crosses. ",
-                f"With k={k}, the maximum number of crosses is {max_crosses}",
-            )
-        self.n_crosses = n_crosses
-
-        if self.n_crosses > self.individual_per_gen:
-            raise ValueError(
-                "Invalid combination for k and n_crosses. ",
-                f"Resulting population size will be {n_crosses} ",
-                f"that is grater than {self.individual_per_gen}",
-            )
+        # same rules and defaults as vec_wrappers.py:27-51 (a tenth of the generation; every pair of the half
+        # diallel among them), same exception type; the messages are this package's own
+        n = self.individual_per_gen
+        self.k = n // 10 if k is None else int(k)
+        if self.k > n:
+            raise ValueError(f"k={self.k} parents cannot be chosen among the {n} individuals of a generation")
+        pairs = self.k * (self.k - 1) // 2
+        self.n_crosses = pairs if n_crosses is None else int(n_crosses)
+        if self.n_crosses > pairs:
+            raise ValueError(f"n_crosses={self.n_crosses}, but k={self.k} parents form only {pairs} distinct pairs")
+        if self.n_crosses > n:
+            raise ValueError(f"n_crosses={self.n_crosses} crosses do not fit the {n} offspring slots of a generation")
         if self.n_crosses < 1:
-            raise ValueError("Incompatible value for k and n_crosses: no pair to cross")
+            raise ValueError(f"k={self.k} parents leave no pair to cross")
 
         self.single_action_space = spaces.Box(-1e5, 1e5, shape=(self.individual_per_gen,))
         self.action_space = spaces.Box(-1e5, 1e5, shape=(self.num_envs, self.individual_per_gen))

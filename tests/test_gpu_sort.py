@@ -1,0 +1,117 @@
+"""GPU: the draws and rankings that no longer fit one workgroup's LDS -- JAX's sort-based shuffle as radix sorts in
+HBM (csrc/sort_kernels.h) -- against the CPU oracle, bit-exact, through the C ABI: the founder draw of
+`VecBreedGym.reset` (breedgym/vector/vec_env.py:22-27) on large germplasm, `SelectionScores._convert_actions`
+(breedgym/vector/vec_wrappers.py:61-79) at the shapes BASELINE's configs[2] and configs[3] give it with the
+reference's default k = n // 10, and `lax.top_k` with more than 16384 winners."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["original", "partitionable"])
+def layout(request):
+    co.set_threefry_layout(request.param)
+    yield request.param
+    co.set_threefry_layout("original")
+
+
+def tiny_engine(layout):
+    from breedgym_amd import HipEngine
+
+    return HipEngine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32), threefry_layout=layout)
+
+
+@pytest.mark.parametrize("N,n,E", [(8193, 50, 2), (10000, 10000, 3), (16385, 4096, 2), (65536, 8192, 2),
+                                     (65536, 65536, 1), (100001, 1000, 5), (1 << 20, 4096, 1)])
+def test_founder_draw_large_germplasm(N, n, E, layout):
+    eng = tiny_engine(layout)
+    key0 = co.key_from_seed(1234)
+    got, key = eng.founders(key0, E, N, n)
+    ref, refkey = co.founders(key0, E, N, n)
+    assert np.array_equal(got.cpu().numpy().reshape(E, n), ref), (N, n, E)
+    assert np.array_equal(key, refkey)
+
+
+def test_founder_draw_through_the_env_window(layout):
+    """envs [2, 5) of 7 draw what envs 2..4 of the whole would (bh_set_env_window), on the radix-sort route"""
+    eng = tiny_engine(layout)
+    N, n = 20000, 777
+    key0 = co.key_from_seed(99)
+    ref, refkey = co.founders(key0, 7, N, n)
+    eng.set_env_window(2, 7)
+    got, key = eng.founders(key0, 3, N, n)
+    assert np.array_equal(got.cpu().numpy().reshape(3, n), ref[2:5])
+    assert np.array_equal(key, refkey)
+
+
+@pytest.mark.parametrize("E,n,k,nc", [(3, 300, 200, 300),        # 19,900 pairs: two rounds, three tiles
+                                        (4, 2048, 204, 2048),      # configs[2] with the reference's default k
+                                        (2, 9000, 40, 780),        # n beyond the LDS kernel, pairs inside it
+                                        (2, 20000, 1000, 5000),    # top-k by radix select, 499,500 pairs
+                                        (1, 65536, 6553, 8192)])   # configs[3]: 21.5 M pairs, three rounds
+def test_selection_actions_large(E, n, k, nc, layout, rng):
+    eng = tiny_engine(layout)
+    s = rng.standard_normal((E, n)).astype(np.float32)
+    s[:, 5] = s[:, 11]  # a tie inside or at the edge of the top-k
+    s[:, n // 2] = s[:, 0]
+    key0 = co.key_from_seed(31)
+    got, key = eng.selection_actions(torch.from_numpy(s), k, nc, key0)
+    ref, refkey = co.selection_actions(s, k, nc, key0)
+    assert np.array_equal(got.cpu().numpy(), ref), (E, n, k, nc)
+    assert np.array_equal(key, refkey)
+
+
+def test_selection_actions_large_through_the_env_window(rng):
+    eng = tiny_engine("original")
+    E, n, k, nc = 5, 2048, 204, 1024
+    s = rng.standard_normal((E, n)).astype(np.float32)
+    key0 = co.key_from_seed(8)
+    ref, refkey = co.selection_actions(s, k, nc, key0)
+    eng.set_env_window(1, E)
+    got, key = eng.selection_actions(torch.from_numpy(s[1:4]), k, nc, key0)
+    assert np.array_equal(got.cpu().numpy(), ref[1:4])
+    assert np.array_equal(key, refkey)
+
+
+@pytest.mark.parametrize("rows,n,k", [(1, 100000, 20000), (3, 40000, 16385), (2, 65536, 65536)])
+def test_topk_more_winners_than_lds(rows, n, k, rng):
+    eng = tiny_engine("original")
+    s = rng.standard_normal((rows, n)).astype(np.float32)
+    s[:, ::7] = np.round(s[:, ::7], 1)  # many exact ties
+    s[0, 3], s[0, 4] = np.inf, -np.inf
+    got = eng.topk(torch.from_numpy(s), k).cpu().numpy()
+    for r in range(rows):
+        assert np.array_equal(got[r], co.topk(s[r], k))
+
+
+def test_selection_scores_env_with_reference_defaults_at_c3():
+    """SelectionScores(VecBreedGym(configs[2])) with the reference's defaults: k = n // 10 = 204 gives 20,706 pairs --
+    more than the generation's 2048 slots, a ValueError like the reference's (vec_wrappers.py:46-51); with
+    n_crosses = n the wrapper steps, and its low-level actions are the oracle's."""
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector import SelectionScores
+
+    E, n, N, M = 4, 2048, 2048, 100_000
+    gm = synthetic_genetic_map(M, n_chr=21, seed=3)
+    geno = synthetic_genotypes(N, M, seed=4)
+    base = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, genetic_map=gm, num_generations=3)
+    with pytest.raises(ValueError):
+        SelectionScores(base)
+    env = SelectionScores(base, n_crosses=n)
+    assert env.k == 204
+    _, infos = env.reset(seed=5)
+    _, env_key = co.founders(co.key_from_seed(5), E, N, n)
+    for _ in range(2):  # SelectionScores.step, taken apart to see the low-level actions
+        scores = infos["GEBV"][..., 0]
+        ref_low, env_key = co.selection_actions(np.asarray(scores), env.k, n, env_key)
+        low = env._convert_actions(scores)
+        assert np.array_equal(low.cpu().numpy(), ref_low)
+        assert np.array_equal(np.asarray(env.random_key), env_key)
+        _, _, _, _, infos = env.env.step(low)
+    obs, rew, ter, tru, infos = env.step(infos["GEBV"][..., 0])  # ... and whole: the horizon step
+    assert tru.all() and obs.shape == (E, n, M, 2)
