@@ -136,6 +136,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   BH_HIP_C(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), sizeof(uint32_t), hipHostMallocMapped));
   *c->h_err = 0u;
   BH_HIP_C(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_err), c->h_err, 0));
+  BH_HIP_C(hipMalloc(&c->d_spare, 16384));
   BH_HIP_C(hipMalloc(&c->d_thrA, nthr * sizeof(uint32_t)));
   BH_HIP_C(hipMalloc(&c->d_thrB, nthr * sizeof(uint32_t)));
   BH_HIP_C(hipMalloc(&c->d_eff, eff.size() * sizeof(double)));
@@ -267,6 +268,7 @@ int bh_destroy(bh_ctx *c) {
     if (c->d_Z[i]) (void)hipFree(c->d_Z[i]);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->d_S) (void)hipFree(c->d_S);
+  if (c->d_spare) (void)hipFree(c->d_spare);
   if (c->d_sort) (void)hipFree(c->d_sort);
   if (c->d_best) (void)hipFree(c->d_best);
   if (c->d_pk) (void)hipFree(c->d_pk);
@@ -294,8 +296,15 @@ int bh_destroy(bh_ctx *c) {
 }
 
 int bh_set_stream(bh_ctx *c, void *hip_stream) {
-  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
-  c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  if (int rc = check_ctx(c)) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  if (s == c->stream) return BH_OK;
+  // what the old stream still owes -- masks made ahead for the next call, a deferred founder draw, scratch in
+  // use -- is finished before the new stream may touch it
+  if (int rc = flush_founders(c)) return rc;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  c->stream = s;
+  c->primed_reward = nullptr;  // a buffer primed on the old stream is primed again
   return BH_OK;
 }
 
@@ -383,7 +392,8 @@ int bh_set_env_window(bh_ctx *c, int64_t env_offset, int64_t envs_total) {
     return fail(BH_ERR_BAD_ARG, "bh_set_env_window: need 0 <= env_offset < envs_total (or 0, 0)");
   c->env_offset = envs_total > 0 ? env_offset : 0;
   c->envs_total = envs_total;
-  c->pf.valid = false;
+  // masks made ahead stay: they carry the key window they were drawn for, and a call under another window does
+  // not match them (cross_impl)
   return BH_OK;
 }
 
@@ -394,7 +404,6 @@ int bh_set_cross_window(bh_ctx *c, int64_t cross_offset, int64_t crosses_total) 
     return fail(BH_ERR_BAD_ARG, "bh_set_cross_window: need 0 <= cross_offset < crosses_total (or 0, 0)");
   c->cross_offset = crosses_total > 0 ? cross_offset : 0;
   c->crosses_total = crosses_total;
-  c->pf.valid = false;
   return BH_OK;
 }
 

@@ -388,6 +388,7 @@ bh::PackedParams packed_params(const bh_ctx *c) {
   p.nvec = c->nvec;
   p.nvp = 8 * c->nw;
   p.T = (int32_t)c->T;
+  p.spare = c->d_spare;
   return p;
 }
 
@@ -571,7 +572,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // with an atomic max into a buffer that holds -inf -- left so by the launch before (d_reward_next of that
     // call), or set so now
     const bool reward_in_launch = d_reward && fused;
-    if (reward_in_launch && !(c->primed_reward == d_reward && c->primed_envs == n_envs)) {
+    if (reward_in_launch && !(c->primed_reward == d_reward && c->primed_envs == n_envs && c->primed_pitch == reward_pitch)) {
       hipLaunchKernelGGL(bh::prime_reward_kernel, dim3(1), dim3(256), 0, c->stream, d_reward, (int)n_envs, reward_pitch);
       BH_HIP(hipGetLastError());
     }
@@ -676,11 +677,13 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     }
     c->primed_reward = d_reward_next;
     c->primed_envs = d_reward_next ? n_envs : 0;
+    c->primed_pitch = reward_pitch;
   } else if (d_reward_next && n_envs > 0) {
     hipLaunchKernelGGL(bh::prime_reward_kernel, dim3(1), dim3(256), 0, c->stream, d_reward_next, (int)n_envs, reward_pitch);
     BH_HIP(hipGetLastError());
     c->primed_reward = d_reward_next;
     c->primed_envs = n_envs;
+    c->primed_pitch = reward_pitch;
   }
   sim_key[0] = nk.x;
   sim_key[1] = nk.y;

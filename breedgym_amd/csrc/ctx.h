@@ -58,6 +58,7 @@ struct bh_ctx {
   // masks of generation g+1 in d_Z[1 - cur] (cross_kernel's two roles)
   uint8_t *d_Z[2] = {nullptr, nullptr};
   int64_t z_cap[2] = {0, 0};  // bytes
+  char *d_spare = nullptr;    // 16 KB nobody reads (PackedParams::spare)
   uint64_t *d_S = nullptr;    // site words of the stream-per-lane mask role (mask_stream.h)
   uint16_t *d_pk = nullptr;   // bit planes of byte-layout rows on their way to gebv_bits (gebv_chunks)
   int64_t pk_cap = 0;         // bytes
@@ -101,7 +102,7 @@ struct bh_ctx {
   bool founders_pending = false;
   // reward chaining (bh_cross*): the buffer the last launch left holding -inf, ready to take atomic maxima
   const float *primed_reward = nullptr;
-  int64_t primed_envs = 0;
+  int64_t primed_envs = 0, primed_pitch = 0;
   bool big_lds_set = false;
   bool select_lds_set = false;
   // device-side error word: host memory the kernels can write (a hand-off wait that ran out, row_kernels.h)

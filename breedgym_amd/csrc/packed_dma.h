@@ -17,7 +17,9 @@
 //
 // The compiler is kept out of the counting: the LDS reads are inline asm (hipcc would otherwise wait for the newest
 // DMA, i.e. for everything), the DMA block is pinned between scheduling barriers, and the count assumes the least
-// number of later operations any schedule inside a trip could leave (a stricter wait, never a looser one).
+// number of later operations any schedule inside a trip could leave.  That only holds if every trip issues the same
+// ST stores and DT DMAs: none of them is predicated (lanes past a row's end store to a spare line; lane 0 of a DMA is
+// always inside the row), which tests/test_isa.py checks in the emitted ISA of the shipped kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -142,13 +144,13 @@ __device__ __forceinline__ void packed_dma_role(const PackedParams &p, const int
   auto dma_next = [&](int slot) {
     const int piece = 64 * dk + lane;
     char *dst = ring + slot * SLOT_BYTES;  // wave-uniform
-    if (piece < npieces) {  // lane 0 always is: the instructions are issued every time
-      const uint32_t off = 16u * (uint32_t)piece;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(a0 + off), (lds_ptr_t)dst, 16, 0, 0);
-      if constexpr (CROSS) {
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(a1 + off), (lds_ptr_t)(dst + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(az + off), (lds_ptr_t)(dst + 2048), 16, 0, 0);
-      }
+    // never predicated (the counted waits rely on every trip issuing DT of these): lanes past the row's end fetch
+    // its last piece again, into LDS words of their own that only the spare-line stores ever look at
+    const uint32_t off = 16u * (uint32_t)(piece < npieces ? piece : npieces - 1);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(a0 + off), (lds_ptr_t)dst, 16, 0, 0);
+    if constexpr (CROSS) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(a1 + off), (lds_ptr_t)(dst + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(az + off), (lds_ptr_t)(dst + 2048), 16, 0, 0);
     }
     if (dk + 1 < n_chunks) {
       ++dk;
@@ -218,13 +220,17 @@ __device__ __forceinline__ void packed_dma_role(const PackedParams &p, const int
 #pragma unroll
         for (int u = 0; u < 8; ++u) store_obs(db + (v16 + 1024u * u), expand_vector(word(u)));
       }
-    } else {  // a row's last chunk
-      if (piece < npieces) *reinterpret_cast<uint4 *>(dp + 16u * (uint32_t)piece) = po;
+    } else {
+      // A row's last chunk.  The counted waits above rely on EVERY trip issuing ST stores: a store whose lanes are
+      // all past the row's end would be branched over (s_cbranch_execz) and never counted, so no store is
+      // predicated here -- the lanes past the end send theirs to a spare line instead (p.spare, 16 KB, never read).
+      char *spare = p.spare + 16u * (uint32_t)lane;
+      *reinterpret_cast<uint4 *>(piece < npieces ? dp + 16u * (uint32_t)piece : spare + 8192) = po;
       if constexpr (OBS) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int w = 512 * t + 64 * u + lane;
-          if (w < p.nvec) store_obs(db + 16u * (uint32_t)w, expand_vector(word(u)));
+          store_obs(w < p.nvec ? db + 16u * (uint32_t)w : spare + 1024 * u, expand_vector(word(u)));
         }
       }
     }

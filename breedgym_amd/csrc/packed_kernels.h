@@ -57,6 +57,8 @@ struct PackedParams {
   float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
   int64_t reward_pitch;  // floats between the words of two envs in both (RowParams)
   int32_t n_envs;
+  char *spare;  // 16 KB nobody reads: where the lanes past a row's end send their stores in the LDS-DMA stream
+                // (packed_dma.h), so that every trip issues the same number of memory operations
 };
 
 // dword k of byte-layout vector v from its packed word: bits 4k .. 4k+3 are its four bytes; the

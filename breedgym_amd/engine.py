@@ -410,5 +410,29 @@ class HipEngine(EngineBase):
         """Run-ahead of the next generation's crossover masks on a side stream (default on)."""
         _lib.check(self._L.bh_set_mask_prefetch(self._h, int(bool(enable))))
 
+    def set_stream(self, stream=None) -> None:
+        """Enqueue this engine's launches on ``stream`` (a ``torch.cuda.Stream``; None = the default stream).
+        Tensors the calls use must belong to that stream as far as torch's caching allocator is concerned: make the
+        calls while it is torch's current stream (``on_stream`` does both) or ``record_stream`` them."""
+        handle = 0 if stream is None else int(stream.cuda_stream)
+        _lib.check(self._L.bh_set_stream(self._h, ctypes.c_void_p(handle or None)))
+        self._stream = stream
+
+    def on_stream(self, stream):
+        """Context manager: the engine's launches AND torch's allocations go to ``stream`` inside the block."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev = getattr(self, "_stream", None)
+            self.set_stream(stream)
+            try:
+                with torch.cuda.stream(stream):
+                    yield self
+            finally:
+                self.set_stream(prev)
+
+        return scope()
+
     def sync(self) -> None:
         _lib.check(self._L.bh_sync(self._h))

@@ -78,6 +78,12 @@ class Simulator:
         else:
             self.engine = HipEngine(gm.recombination_vec, gm.marker_effects, device, threefry_layout)
         if mutation != 0.0:  # chromax's per-allele flip probability; 0 keeps the fused launch
+            import warnings
+
+            warnings.warn(
+                "Simulator(mutation=p): the flip semantics (key split order, one uniform per allele of the finished "
+                "gamete) restate chromax from memory and are not pinned by any reference-held vector "
+                "(INTEGRATION.md section 4 has the script that would pin them)", stacklevel=2)
             self.engine.set_mutation(mutation)
         self.device = self.engine.device
         self.GEBV_model = TraitModel(self, gm.marker_effects)

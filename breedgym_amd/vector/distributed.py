@@ -12,10 +12,11 @@ Two ways the hot path shards:
   65,536 individuals x 100k markers) split row-wise over the ranks.  Per generation:
   local GEBV -> local top-k -> all-gather of (score, global index) candidates (8 B x k per rank)
   -> every rank computes the same global top-k -> the winners' genotype rows are replicated with ONE
-  all-reduce of a (k, row) buffer in which every rank has filled the rows it owns and zeroed the rest
-  (each row has exactly one owner, so the sum is the row: no counts to exchange, no host sync, no
-  padding to a largest share) -> each rank crosses its own shard of the next generation from that
-  buffer.  The scalar best-GEBV reward is a MAX all-reduce.
+  all-gather: every rank sends the winners it owns, padded to the largest share (the global index list is
+  identical everywhere, so every rank derives all counts and offsets from it -- nothing but the rows is
+  exchanged; (N-1)/N of the rows per rank on the wire, half of what an all-reduce of a zero-padded buffer
+  moves) -> each rank crosses its own shard of the next generation straight from the gathered buffer
+  (parent indices are remapped, rows are never permuted).  The scalar best-GEBV reward is a MAX all-reduce.
 
 Both are **world-size invariant**: N ranks compute, shard by shard, exactly what one device would
 compute for the whole -- the engine's sharding windows (include/breedhip.h) make every rank draw the
@@ -126,7 +127,6 @@ class ShardedPopulation:
         self._store = self.eng.pack(local_rows) if storage == "bits" else local_rows
         self.n_local = local_rows.shape[0]
         self.n_total = self.n_local * self.world_size
-        self.eng.set_cross_window(self.rank * self.n_local, self.n_total)
 
     @property
     def rows(self) -> torch.Tensor:
@@ -171,28 +171,39 @@ class ShardedPopulation:
         best = self.eng.topk(cand_s.reshape(-1), k).to(torch.int64)
         return cand_i.reshape(-1)[best]
 
-    def replicate_winners(self, global_idx: torch.Tensor) -> torch.Tensor:
-        """The rows of ``global_idx`` (k,), in that order, on every rank -- (k, row bytes) in the storage layout.
+    def replicate_winners(self, global_idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The rows of ``global_idx`` (k,) on every rank: ``(pool, pos)`` with winner j in row ``pos[j]`` of
+        ``pool`` (rows in the storage layout).
 
-        Every rank fills the rows it owns into a zeroed (k, row) buffer (a masked gather: rows it does not own
-        are written as zeros) and ONE all-reduce (sum over int32 words; every row has exactly one owner) makes
-        the buffer whole everywhere.  ``global_idx`` is identical on all ranks; nothing goes through the host."""
+        Winners are owned by contiguous index ranges, and ``global_idx`` is identical on all ranks: every rank
+        counts, from that list alone, how many winners each rank owns.  Each rank gathers ITS winners (in list
+        order) into a send block padded to the largest share and ONE all-gather of those blocks replicates
+        them: (N-1)/N of the rows per rank on the wire.  The blocks are not re-ordered afterwards -- ``pos``
+        says where a winner landed -- so the only extra traffic is the padding (top-k winners spread evenly:
+        a few per cent).  One small device-to-host copy (the N counts) sizes the blocks."""
         k = global_idx.numel()
-        local = global_idx - self.rank * self.n_local
-        mine = (local >= 0) & (local < self.n_local)
-        buf = torch.empty((k, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
-        self._gather_local(self._store, local.clamp(0, self.n_local - 1).to(torch.int32).contiguous(), buf)
         if self.world_size == 1:
-            return buf
-        words = buf.view(torch.int32)  # row bytes are a multiple of 16
-        words.mul_(mine.to(torch.int32).unsqueeze(1))
-        dist.all_reduce(words, op=dist.ReduceOp.SUM, group=self.group)
-        return buf
+            buf = torch.empty((k, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
+            self._gather_local(self._store, global_idx.to(torch.int32).contiguous(), buf)
+            return buf, torch.arange(k, device=buf.device)
+        owner = torch.div(global_idx, self.n_local, rounding_mode="floor")
+        hot = torch.nn.functional.one_hot(owner, self.world_size)  # (k, W)
+        within = (hot.cumsum(0) - hot).gather(1, owner.unsqueeze(1)).squeeze(1)  # earlier winners of the same owner
+        counts = hot.sum(0).cpu()
+        cmax = int(counts.max())
+        mine = owner == self.rank
+        send_idx = torch.zeros((cmax,), dtype=torch.int32, device=self._store.device)  # padding: row 0 again
+        send_idx[: int(counts[self.rank])] = (global_idx[mine] - self.rank * self.n_local).to(torch.int32)
+        block = torch.empty((cmax, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
+        self._gather_local(self._store, send_idx, block)
+        pool = self._all_gather(block).reshape(self.world_size * cmax, -1)
+        return pool, owner * cmax + within
 
     def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
         """The genotype rows of `global_idx` (k,), in that order, replicated on every rank (byte layout)."""
-        pool = self.replicate_winners(global_idx)
-        return self.eng.unpack(pool) if self.storage == "bits" else pool
+        pool, pos = self.replicate_winners(global_idx)
+        rows = pool.index_select(0, pos)
+        return self.eng.unpack(rows) if self.storage == "bits" else rows
 
     def select_and_cross(self, k: int, pairs_local: torch.Tensor, key: np.ndarray) -> DeviceArray:
         """One generation: global top-k by GEBV (first trait), replicate the winners, cross this rank's
@@ -200,14 +211,21 @@ class ShardedPopulation:
         ``key`` is the simulator key, THE SAME on every rank, advanced in place as one device would."""
         scores = self.gebv()[:, 0]
         best = self.global_topk(scores, k)
-        pool = self.replicate_winners(best)
+        pool, pos = self.replicate_winners(best)
         gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
-        idx = pairs_local.to(device=pool.device, dtype=torch.int32).reshape(1, -1, 2).contiguous()
-        if self.storage == "bits":
-            out = self.eng.empty_packed(self.n_local)
-            self.eng.cross_packed(pool, 1, k, idx, self.n_local, key, 1, out, None, gebv)
-        else:
-            out = self.eng.empty_population(self.n_local)
-            self.eng.cross(pool, 1, k, idx, self.n_local, key, 1, out, gebv)
+        # winner j sits in row pos[j] of the gathered buffer: point the pairs there instead of moving rows
+        idx = pos[pairs_local.to(device=pool.device, dtype=torch.int64)].to(torch.int32).reshape(1, -1, 2).contiguous()
+        # this rank's crosses are crosses [rank * n_local, ...) of ONE batch of n_total: the window is set for
+        # this call only (the simulator's engine is shared with whoever else crosses on it)
+        self.eng.set_cross_window(self.rank * self.n_local, self.n_total)
+        try:
+            if self.storage == "bits":
+                out = self.eng.empty_packed(self.n_local)
+                self.eng.cross_packed(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, None, gebv)
+            else:
+                out = self.eng.empty_population(self.n_local)
+                self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
+        finally:
+            self.eng.set_cross_window(0, 0)
         self._store = out
         return DeviceArray.wrap(gebv)

@@ -75,6 +75,11 @@ int bh_device_count(int *count);
 int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *recomb_vec,
               const float *effects, bh_ctx **out);
 int bh_destroy(bh_ctx *ctx);
+/* Move the context to another HIP stream (hipStream_t; NULL = the null stream).  Work already enqueued on the old
+ * stream is waited for first.  Every device buffer handed to later calls must be safe to use on that stream: with a
+ * caching allocator (torch) allocate it while that stream is current, or record it to the stream
+ * (Tensor.record_stream) -- a block the allocator recycles on another stream while a launch still reads it is the
+ * caller's race, not the library's. */
 int bh_set_stream(bh_ctx *ctx, void *hip_stream);
 int bh_sync(bh_ctx *ctx);
 int64_t bh_row_pitch(const bh_ctx *ctx);
@@ -114,7 +119,10 @@ int bh_download_population(bh_ctx *ctx, const uint8_t *d_src, int64_t rows, uint
  *                                           before (and nothing wrote to it since), otherwise the
  *                                           library fills it first; elsewhere a reduction kernel follows
  *   d_reward_next (n_envs) f32 or NULL      left holding -inf by this launch, for the caller to pass as
- *                                           d_reward of its next call (saves that fill)
+ *                                           d_reward of its next call (saves that fill).  The library recognises
+ *                                           it by address, length and pitch: between the two calls the caller must
+ *                                           neither write to it nor free it (a freed block can come back from an
+ *                                           allocator at the same address with other contents)
  *   reward_pitch                            floats from one env's word to the next in d_reward and
  *                                           d_reward_next (>= 1; 64 gives every env a cache line of its own,
  *                                           so that the atomics of different envs do not queue behind each other)
@@ -149,7 +157,8 @@ int bh_reward_max(bh_ctx *ctx, const float *d_gebv, int64_t n_envs, int64_t per_
 
 /* `jax.lax.top_k(scores, k)[1]` (vec_wrappers.py:64; Simulator.select): for each of n_rows
  * score vectors of length n, the indices of the k largest in descending order, ties to the
- * lower index.  d_scores (n_rows, n) f32; d_idx_out (n_rows, k) int32. */
+ * lower index (order = XLA's total order of the bit patterns: -0 below +0).  d_scores (n_rows, n) f32;
+ * d_idx_out (n_rows, k) int32.  Any k <= n (above 16384 winners: a radix sort of the row in HBM). */
 int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64_t k,
             int32_t *d_idx_out);
 
@@ -157,7 +166,9 @@ int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64
  * k best by score, a random subset of n_crosses of their k(k-1)/2 diallel pairs (without
  * replacement, key = split(env_key, E+1)[1+e]), each repeated ceil(n / n_crosses) times and cut to
  * n.  d_scores (E, n) f32 -> d_actions (E, n, 2) int32; env_key is advanced like the wrapper's
- * `random_key` (keys[0]).  n <= 8192 and k(k-1)/2 <= 8192. */
+ * `random_key` (keys[0]).  Up to n <= 8192 and k(k-1)/2 <= 8192 one workgroup per env does it all in LDS; beyond
+ * (the reference's default k = n // 10 at 2048 individuals already is: 20,706 pairs; 65,536 individuals give
+ * 21.5 M pairs and three shuffle rounds) the pair ranks are shuffled by radix sorts in HBM.  k(k-1)/2 < 2^31. */
 int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
                          int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
 
@@ -228,8 +239,9 @@ int bh_permutation(const uint32_t key[2], int64_t n, int layout, int32_t *out);
 int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_t n, int layout,
                 int32_t *out);
 
-/* The same draw made on the device (one workgroup per env: Threefry + bitonic sort in LDS),
- * written to d_out (E, n) int32 in stream order; env_key is advanced on the host. */
+/* The same draw made on the device, written to d_out (E, n) int32 in stream order; env_key is advanced on the
+ * host.  Germplasm up to 8192 rows: one workgroup per env, Threefry + bitonic sort in LDS; larger (to 2^31 - 1
+ * rows): the shuffle rounds as stable radix sorts in HBM, envs side by side -- nothing goes through the host. */
 int bh_founders_device(bh_ctx *ctx, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm,
                        int64_t n, int32_t *d_out);
 

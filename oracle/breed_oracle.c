@@ -179,9 +179,19 @@ typedef struct {
   int32_t i;
 } si_t;
 
+/* jax.lax.top_k orders by XLA's total order on the bit patterns, -NaN < -inf < -0 < +0 < +inf < +NaN (xla's TopK
+ * compares the floats as sign-magnitude integers so that the result is deterministic), equal patterns to the lower
+ * index.  [EXTERNAL: XLA is not in the reference tree]  Only -0 vs +0 and NaNs differ from a plain float compare. */
+static int32_t si_total_order(float f) {
+  uint32_t u;
+  memcpy(&u, &f, sizeof u);
+  return (int32_t)u < 0 ? (int32_t)(0x7FFFFFFFu - u) : (int32_t)u; /* wraps to -1 - |f| for negative patterns */
+}
+
 static int si_cmp(const void *a, const void *b) {
   const si_t *x = (const si_t *)a, *y = (const si_t *)b;
-  if (x->s != y->s) return x->s > y->s ? -1 : 1;
+  const int32_t vx = si_total_order(x->s), vy = si_total_order(y->s);
+  if (vx != vy) return vx > vy ? -1 : 1;
   return x->i < y->i ? -1 : (x->i > y->i);
 }
 

@@ -158,7 +158,10 @@ def reward_max(g):
 
 
 def topk(scores, k):
-    return np.argsort(-np.asarray(scores, np.float32), kind="stable")[:k].astype(np.int32)
+    """jax.lax.top_k: descending in XLA's total order of the bit patterns (-0 below +0), ties to the lower index."""
+    u = np.ascontiguousarray(scores, np.float32).view(np.uint32).astype(np.int64)
+    order = np.where(u >> 31, 0x7FFFFFFF - u, u)  # sign-magnitude -> two's complement
+    return np.argsort(-order, kind="stable")[:k].astype(np.int32)
 
 
 def selection_actions(scores, k, n_crosses, env_key):

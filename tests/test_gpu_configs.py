@@ -537,3 +537,87 @@ def test_many_long_rows_stream_mask_role(layout, mode, M, rng):
         eng.sync()
     finally:
         co.set_threefry_layout("original")
+
+
+@pytest.mark.parametrize("M", [16385, 17000, 17920])
+def test_dma_stream_short_last_chunks_soak(M, rng):
+    """Rows of exactly five 4096-marker chunks whose last chunk fills at most three of its eight slices
+    (16384 < M <= 17920): the shape in which the LDS-DMA stream's counted `vmcnt` wait used to lean on timing (a
+    store with no active lane is never issued, hence never counted; csrc/packed_dma.h now sends those lanes to a
+    spare line).  8200 rows, 50 cross launches down the key chain (observation written on even launches, not on odd
+    ones) and 50 founder gathers, every launch compared on the device with the oracle's rows / the gathered rows."""
+    from breedgym_amd import HipEngine
+
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    E, n, NP = 2, 4100, 23
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    r = (rng.random(M) * 0.004).astype(np.float32)
+    r[:: M // 21] = 0.5
+    eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+    eng = HipEngine(r, eff)
+
+    def packed_rows(g):  # (rows, M, 2) bytes -> the library's bit-plane rows (include/breedhip.h), on the device
+        bits = np.packbits(g.reshape(g.shape[0], 2 * M), axis=1, bitorder="little")
+        out = np.zeros((g.shape[0], eng.packed_pitch), np.uint8)
+        out[:, : bits.shape[1]] = bits
+        return torch.from_numpy(out).to(eng.device)
+
+    packed = eng.pack(eng.upload_population(pool.reshape(E * NP, M, 2)))
+    assert torch.equal(packed, packed_rows(pool.reshape(E * NP, M, 2)))
+    key, ref_key = co.key_from_seed(77).copy(), co.key_from_seed(77)
+    for it in range(50):
+        idx = rng.integers(0, NP, (E, n, 2), dtype=np.int32)
+        outp = eng.empty_packed(E * n)
+        ob = eng.empty_population(E * n) if it % 2 == 0 else None
+        eng.cross_packed(packed, E, NP, torch.from_numpy(idx).to(eng.device), n, key, 0, outp, ob, None)
+        ref, ref_key = co.cross(pool, idx, r, ref_key, 0)
+        assert torch.equal(outp, packed_rows(ref.reshape(E * n, M, 2))), f"cross launch {it}"
+        if ob is not None:
+            assert torch.equal(ob, eng.unpack(outp)), f"observation of cross launch {it}"
+        assert np.array_equal(key, ref_key)
+    src = packed_rows(rng.integers(0, 2, (300, M, 2), dtype=np.uint8))
+    for it in range(50):
+        gi = torch.from_numpy(rng.integers(0, 300, 8200).astype(np.int32)).to(eng.device)
+        outp = eng.empty_packed(8200)
+        ob = eng.empty_population(8200) if it % 2 == 0 else None
+        eng.gather_packed(src, gi, 8200, outp, ob)
+        assert torch.equal(outp, src[gi.long()]), f"gather launch {it}"
+        if ob is not None:
+            assert torch.equal(ob, eng.unpack(outp)), f"observation of gather launch {it}"
+    eng.sync()
+
+
+def test_c1_single_env_at_shape():
+    """BASELINE configs[0] at its real shape on the device: single-env `BreedGym`, 370 individuals x 10k markers,
+    16 random crosses per generation, 10 generations, the reward (mean GEBV, breedgym.py:151-155) at the horizon --
+    the loop of the reference's tests/test_env.py:103-119 -- every population byte for byte and every GEBV against
+    the chain founders -> co.cross -> co.cross ...; then a second episode after reset()."""
+    from breedgym_amd import BreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N, M, C, G = 370, 10_000, 16, 10
+    gm = synthetic_genetic_map(M, n_chr=10, seed=1)
+    geno = synthetic_genotypes(N, M, seed=0)
+    env = BreedGym(initial_population=geno, genetic_map=gm, reward_shaping=False, num_generations=G)
+    assert type(env.simulator.engine).__name__ == "HipEngine"
+    arng = np.random.default_rng(2)
+    key = None
+    for episode, seed in enumerate((7, None)):
+        pop, info = env.reset(seed=seed) if seed is not None else env.reset()
+        assert pop.shape == (N, M, 2) and np.array_equal(u8(pop), geno.view(np.uint8))
+        if seed is not None:
+            key = co.key_from_seed(seed)  # reset(seed) re-seeds the simulator (breedgym.py:117); reset() keeps the chain
+        ref = geno.view(np.uint8)[None]
+        for g in range(G):
+            action = arng.integers(0, ref.shape[1], (C, 2))
+            pop, rew, ter, tru, info = env.step(action)
+            ref, key = co.cross(ref, action[None].astype(np.int32), gm.recombination_vec, key, 0)
+            assert pop.shape == (C, M, 2) and np.array_equal(u8(pop), ref[0]), (episode, g)
+            g64 = co.gebv(ref[0], gm.marker_effects, want64=True)[1]
+            assert gebv_close(info["GEBV"].to_numpy(), g64)
+            assert np.array_equal(env.simulator.random_key, key)
+            assert not ter and tru == (g == G - 1)
+            if g < G - 1:
+                assert rew == 0
+            else:
+                assert abs(rew - g64.mean()) <= 1e-5 * max(1.0, abs(g64.mean()))

@@ -601,3 +601,37 @@ def test_mask_units_taken_in_turns(M, E, n, mode, rng):
         assert np.array_equal(eng.download_population(outb).view(np.uint8).reshape(E, n, M, 2), ref)
         assert np.array_equal(key, refkey)
         prow, n_pool = outp, n
+
+
+def test_context_on_a_side_stream(rng):
+    """bh_set_stream: launches go to a non-default stream (torch's allocations too: HipEngine.on_stream), results
+    are the oracle's; switching streams keeps the masks made ahead usable (the old stream is waited for)."""
+    M, E, NP, NO = 3000, 3, 20, 700
+    r = (rng.random(M) * 0.01).astype(np.float32)
+    r[0] = 0.5
+    eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+    eng = make_engine(r, eff)
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    idx = rng.integers(0, NP, (E, NO, 2), dtype=np.int32)
+    side = torch.cuda.Stream()
+    key, ref_key = co.key_from_seed(3).copy(), co.key_from_seed(3)
+    busy = torch.empty(64 << 20, dtype=torch.float32, device=eng.device)
+
+    def one_call():
+        nonlocal ref_key
+        rows = eng.pack(eng.upload_population(pool.reshape(E * NP, M, 2)))
+        outp, ob = eng.empty_packed(E * NO), eng.empty_population(E * NO)
+        g = eng.empty((E, NO, 1), torch.float32)
+        eng.cross_packed(rows, E, NP, torch.from_numpy(idx).to(eng.device), NO, key, 0, outp, ob, g)
+        ref, ref_key = co.cross(pool, idx, r, ref_key, 0)
+        eng.sync()  # the context's stream, whichever it is
+        assert np.array_equal(eng.download_population(ob).view(np.uint8).reshape(ref.shape), ref)
+        assert gebv_close(g.cpu().numpy(), co.gebv(ref, eff, want64=True)[1], eff)
+        assert np.array_equal(key, ref_key)
+
+    one_call()  # default stream; leaves masks made ahead
+    with eng.on_stream(side):
+        for _ in range(3):
+            busy.normal_()  # keeps the DEFAULT stream busy: nothing of the context may depend on it
+            one_call()
+    one_call()  # back on the default stream, with the masks the side stream made ahead

@@ -1,0 +1,64 @@
+"""CPU: properties of the emitted gfx950 ISA that the kernels' correctness arguments lean on (hipcc cross-compiles
+without a GPU).
+
+The LDS-DMA row stream (csrc/packed_dma.h) waits for a chunk with a COUNTED `s_waitcnt vmcnt(N)`: N later memory
+operations may still be in flight.  That proves the chunk has landed only if every trip really issues its nine stores
+and three DMAs -- a store whose lanes are all inactive is branched over (`s_cbranch_execz`) and never counted.  So
+inside the stream no store and no DMA may sit behind such a branch; lanes past a row's end store to a spare line
+instead.  This test reads the ISA of the shipped kernels and checks exactly that."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "breedgym_amd" / "csrc"
+
+
+@pytest.fixture(scope="module")
+def cross_isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "cross.s"
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", f"-I{ROOT / 'include'}", "--cuda-device-only",
+                    "-S", str(CSRC / "cross.hip"), "-o", str(out)], check=True, capture_output=True)
+    return out.read_text().split("\n")
+
+
+def kernel_bodies(lines):
+    name, start = None, 0
+    for i, line in enumerate(lines):
+        m = re.match(r"^(_ZN2bh\w+):", line)
+        if m:
+            name, start = m.group(1), i
+        elif name and line.strip().startswith(".Lfunc_end"):
+            yield name, lines[start:i]
+            name = None
+
+
+def test_dma_stream_issues_every_store_and_dma_unconditionally(cross_isa):
+    checked = []
+    for name, body in kernel_bodies(cross_isa):
+        dma = [i for i, l in enumerate(body) if "global_load_lds_dwordx4" in l]
+        if not dma:
+            continue
+        obs = [i for i, l in enumerate(body) if re.search(r"global_store_dwordx4.*\bnt\b", l)]
+        assert len(obs) >= 16, f"{name}: the observation stores of the stream were expected as non-temporal"
+        lo, hi = dma[0], max(dma[-1], obs[-1])  # the stream: from its first DMA to its last DMA / observation store
+        labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+        for i in range(lo, hi + 1):
+            m = re.search(r"s_cbranch_execz\s+(\.LBB\d+_\d+)", body[i])
+            if not m or labels.get(m.group(1), -1) <= i:
+                continue
+            skipped = [body[k].strip() for k in range(i, labels[m.group(1)])
+                       if "global_store" in body[k] or "global_load_lds" in body[k]]
+            assert not skipped, f"{name}: line {i}: an exec-guarded branch skips memory operations of the stream: {skipped}"
+        # the counted waits are there, and nothing in the stream waits for everything (vmcnt(0) belongs to the prologue)
+        waits = [l for l in body[lo:hi] if "s_waitcnt" in l and "vmcnt" in l]
+        assert any("vmcnt(60)" in l or "vmcnt(20)" in l or "vmcnt(10)" in l for l in waits), (name, waits[:8])
+        checked.append(name)
+    # the long-row launch (cross) and the reset's founder gather / a cross without run-ahead
+    assert any("packed_long_kernel" in n for n in checked) and any("packed_row_kernel" in n for n in checked), checked
