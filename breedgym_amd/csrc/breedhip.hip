@@ -61,8 +61,10 @@ int bh_device_count(int *count) {
 }
 
 int64_t bh_max_markers(void) {
-  // LDS per cross ~= M/2 bytes (site words M/4 + interleaved masks M/4); 2^18 markers = 128 KiB
-  return (int64_t)1 << 18;
+  // what the 32-bit offsets inside a row and the tested shapes cover (the reference's largest: 1,406,757 markers,
+  // scripts/time_cross.py:14).  Up to 2^18 markers a cross's site words stay in LDS; beyond, they go through
+  // memory (mask_stream.h)
+  return (int64_t)1 << 22;
 }
 
 int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *recomb_vec,
@@ -72,7 +74,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   if (n_markers <= 0 || n_traits < 0 || !recomb_vec || (n_traits > 0 && !effects))
     return fail(BH_ERR_BAD_ARG, "bh_create: need n_markers > 0, n_traits >= 0 and non-null arrays");
   if (n_markers > bh_max_markers())
-    return fail(BH_ERR_UNSUPPORTED, "bh_create: %lld markers exceed the LDS-staged limit of %lld",
+    return fail(BH_ERR_UNSUPPORTED, "bh_create: %lld markers exceed the supported %lld",
                 (long long)n_markers, (long long)bh_max_markers());
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -195,11 +197,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
             long long d = ((fix % 65536) + 65536) % 65536;
             if (d >= 32768) d -= 65536;
             fix = (fix - d) / 65536;
-#if defined(BH_DIG_INTERLEAVED)
-            dig[(size_t)(((t * c->nvec + (m >> 3)) * 3 + j) * 8 + (m & 7))] = (int16_t)d;
-#else
             dig[(size_t)(((t * 3 + j) * c->nvec + (m >> 3)) * 8 + (m & 7))] = (int16_t)d;
-#endif
           }
         }
       BH_HIP_C(hipMalloc(&c->d_dig16, dig.size() * sizeof(int16_t)));

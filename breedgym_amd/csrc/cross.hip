@@ -18,10 +18,7 @@ int row_waves_for(const bh_ctx *c, int64_t n_rows) { return (c->M > 16384 && n_r
 size_t mask_group_lds(const bh_ctx *c) { return (size_t)(c->nwh + 1) * 32; }  // S[nwh + 1][4] u64
 
 // rows one wave streams at once (the effect vectors are loaded once per trip for all of them)
-#ifndef BH_ROWS_PER_WAVE_CROSS  // tuning experiments only
-#define BH_ROWS_PER_WAVE_CROSS 2
-#endif
-constexpr int kRowsPerWaveCross = BH_ROWS_PER_WAVE_CROSS, kRowsPerWavePlain = 4;
+constexpr int kRowsPerWaveCross = 2, kRowsPerWavePlain = 4;
 
 template <int WAVES, int TT, int MODE, int R>
 int launch_row(const bh_ctx *c, bh::RowParams p) {
@@ -102,8 +99,27 @@ int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
   return BH_OK;
 }
 
+// rows whose site words no longer fit one workgroup's LDS next to everything else (M / 4 bytes: 64 KB here)
+constexpr int64_t kLdsMaskMaxMarkers = (int64_t)1 << 18;
+int ensure_sites(bh_ctx *c, int64_t B);
+
 // crossover masks of B crosses keyed off `key` into d_Z[buf], in stream order (not overlapped)
 int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bool dh, KeyWindow kw) {
+  if (c->M > kLdsMaskMaxMarkers) {
+    // the two phases of the mask role as two kernels with the site words in memory (mask_stream.h): any number
+    // of workgroups per cross draw the sites, one wave per cross runs the prefix-XOR along the row
+    bh::MaskParams m = mask_params(c, buf, key0, key1, B, 4, dh, kw);
+    if (int rc = ensure_sites(c, B)) return rc;
+    m.sites = c->d_S;
+    m.spitch = c->nwh + 1;
+    const int64_t tiles = (c->nwh + bh::kSiteTileTrips - 1) / bh::kSiteTileTrips;
+    if (B * tiles > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "too many crosses x markers for one mask launch");
+    hipLaunchKernelGGL(bh::mask_sites_kernel, dim3((unsigned)(B * tiles)), dim3(256), 0, c->stream, m);
+    hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, c->stream, m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_sites_kernel launch: %s", hipGetErrorString(e));
+    return BH_OK;
+  }
   const int waves = waves_for(c);
   const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves, dh, kw);
   const size_t lds = (size_t)m.group_lds * (4 / waves);
@@ -128,10 +144,7 @@ int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bo
 // long-lived ones (2.49 ms against 2.10 ms at 8192 independent 100k-marker crosses): no turns then.
 // Only for four mask waves per cross: in the one-wave-per-cross kernels the loop costs the registers
 // that keep eight waves per SIMD resident.
-#ifndef BH_MASK_TURNS_MAX  // tuning experiments only (1 = never take turns)
-#define BH_MASK_TURNS_MAX 4
-#endif
-constexpr int kMaskTurnsMax = BH_MASK_TURNS_MAX;
+constexpr int kMaskTurnsMax = 4;  // (1 = never take turns)
 inline int two_role_grid(int row_blocks, int mask_blocks) {
   if (mask_blocks <= row_blocks) return row_blocks;
   return mask_blocks <= kMaskTurnsMax * row_blocks ? row_blocks : mask_blocks;
@@ -163,15 +176,8 @@ int launch_cross_mw(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp
 }
 
 // ---- packed (bit-plane) rows: packed_kernels.h ------------------------------------------------
-// rows one wave streams at once when there are many (BH_PACKED_R: tuning experiments only)
-#ifndef BH_PACKED_R
-#define BH_PACKED_R 2
-#endif
-constexpr int kRowsPerWavePacked = BH_PACKED_R;
-#ifndef BH_LONG_R  // rows a wave interleaves in the long-row stream (tuning experiments only)
-#define BH_LONG_R 1
-#endif
-constexpr int kRowsPerWaveLong = BH_LONG_R;
+constexpr int kRowsPerWavePacked = 2;  // rows one wave streams at once when there are many
+constexpr int kRowsPerWaveLong = 1;    // rows a wave interleaves in the long-row stream
 
 template <int TT, int MW, int R>
 int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
@@ -200,14 +206,12 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
 }
 
 // the launch for many long rows: stream role in turns + stream-per-lane mask role, then the site words -> masks
-#ifndef BH_LONG_MASK_WAVES  // mask waves per workgroup of four row waves (tuning experiments only)
-#define BH_LONG_MASK_WAVES 8
-#endif
+constexpr int kLongMaskWaves = 8;  // mask waves per workgroup of four row waves
 int launch_plong(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   const int per_wave = kRowsPerWaveLong * std::max(1, rp.seq);
   rp.n_blocks = (rp.n_rows + 4 * per_wave - 1) / (4 * per_wave);
-  hipLaunchKernelGGL((bh::packed_long_kernel<kRowsPerWaveLong, BH_LONG_MASK_WAVES>), dim3((unsigned)rp.n_blocks),
-                     dim3(64 * (4 + BH_LONG_MASK_WAVES)), 0, c->stream, rp, mp);
+  hipLaunchKernelGGL((bh::packed_long_kernel<kRowsPerWaveLong, kLongMaskWaves>), dim3((unsigned)rp.n_blocks),
+                     dim3(64 * (4 + kLongMaskWaves)), 0, c->stream, rp, mp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_long_kernel launch: %s", hipGetErrorString(e));
   // site words -> masks, one wave per keyed cross, in stream order (a stream of its own beside the GEBV pass
@@ -274,14 +278,12 @@ int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
 }
 
 // Long bit-plane rows without GEBV in the stream (it follows as the matrix-core pass): a wave streams
-// its rows one after the other, so that about BH_LONG_STREAMS rows are being written at any time
+// its rows one after the other, so that about kLongStreams rows are being written at any time
 // (packed_stream_role).  0 = the ordinary stream.
-#ifndef BH_LONG_STREAMS  // tuning experiments only
-#define BH_LONG_STREAMS 4096
-#endif
+constexpr int kLongStreams = 4096;
 int long_row_turns(const bh_ctx *c, int64_t rows) {
-  if (c->M <= 16384 || rows < 2 * BH_LONG_STREAMS) return 0;
-  return (int)std::min<int64_t>(16, rows / BH_LONG_STREAMS);
+  if (c->M <= 16384 || rows < 2 * kLongStreams) return 0;
+  return (int)std::min<int64_t>(16, rows / kLongStreams);
 }
 
 // site words of B crosses for mask_stream_role: (B, nwh + 1, 4) u64, zero where never written
@@ -393,18 +395,13 @@ bh::PackedParams packed_params(const bh_ctx *c) {
 }
 
 // from this many traits on, the int8-MFMA GEBV pass beats GEBV fused into the row stream
-#ifndef BH_MFMA_GEBV_MIN_TRAITS  // tuning experiments only
-#define BH_MFMA_GEBV_MIN_TRAITS 3
-#endif
-constexpr int kMfmaGebvMinTraits = BH_MFMA_GEBV_MIN_TRAITS;
+constexpr int kMfmaGebvMinTraits = 3;
 bool use_mfma_gebv(const bh_ctx *c, int64_t rows) { return c->T >= kMfmaGebvMinTraits && rows >= 32; }
 // bit-plane rows: the matrix-core pass (gebv_bits.h) also for one or two traits once the rows are long --
 // at 100k markers it takes a quarter of the f64 stream's time (profiles/r02_gebv_bits.txt)
-#ifndef BH_BITS_GEBV_MIN_MARKERS  // tuning experiments only
-#define BH_BITS_GEBV_MIN_MARKERS 16385
-#endif
+constexpr int kBitsGebvMinMarkers = 16385;
 bool use_bits_gebv(const bh_ctx *c, int64_t rows) {
-  return rows >= 32 && (c->T >= kMfmaGebvMinTraits || c->M >= BH_BITS_GEBV_MIN_MARKERS);
+  return rows >= 32 && (c->T >= kMfmaGebvMinTraits || c->M >= kBitsGebvMinMarkers);
 }
 
 // GEBV of rows already in memory, for trait chunks [t_begin, T)
@@ -420,14 +417,12 @@ int launch_pack(bh_ctx *c, const bh::PackParams &p) {
   return BH_OK;
 }
 
-#ifndef BH_GEBV_VIA_BITS_MIN  // rows x markers from which byte-layout rows go through bit planes (tuning experiments only)
-#define BH_GEBV_VIA_BITS_MIN (1ll << 25)
-#endif
+constexpr int64_t kGebvViaBitsMin = 1ll << 25;  // rows x markers from which byte-layout rows go through bit planes
 int gebv_chunks(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
   // large byte-layout populations: to bit planes first (the read of the byte rows at streaming rate, 1/8 of them
   // written), then the matrix-core pass over those (gebv_bits.h) -- 2048 x 100k x 8: 158 -> 115 us; long rows of one
   // or two traits: instead of the f64 stream
-  if (t_begin == 0 && use_bits_gebv(c, rows) && rows * c->M >= BH_GEBV_VIA_BITS_MIN) {
+  if (t_begin == 0 && use_bits_gebv(c, rows) && rows * c->M >= kGebvViaBitsMin) {
     const int64_t bytes = rows * 16 * c->nw;
     if (c->pk_cap < bytes) {
       BH_HIP(hipStreamSynchronize(c->stream));
@@ -559,7 +554,9 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     const int tcount = fused ? (int32_t)c->T : 0;
     // run ahead: the next generation's masks need only the advanced key and the batch size, so
     // the same launch makes them (mask role) while it streams this generation (row role)
-    const bool run_ahead = c->prefetch && (packed || row_waves_for(c, rows) == 1);
+    // (beyond kLdsMaskMaxMarkers only the long-row launch can carry the mask role: it keeps no site words in LDS)
+    const bool run_ahead = c->prefetch && (packed || row_waves_for(c, rows) == 1) &&
+                           (c->M <= kLdsMaskMaxMarkers || long_stream);
     bh::MaskParams mp{};
     int mw = 1;
     if (run_ahead) {
@@ -601,14 +598,10 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
           rc = wide ? launch_pcross_mw<1, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<1, 1>(c, p, mp, tt_for(tcount));
         else if (turns > 1) {
-#if !defined(BH_NO_MASK_STREAM)  // tuning experiments only: the LDS mask role next to the long-row stream
           if (int rc2 = ensure_sites(c, B)) return rc2;
           mp.sites = c->d_S;
           mp.spitch = c->nwh + 1;
           rc = launch_plong(c, p, mp);
-#else
-          rc = launch_pcross_mw<4, kRowsPerWaveLong>(c, p, mp, 0);
-#endif
         }
         else
           rc = wide ? launch_pcross_mw<4, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))

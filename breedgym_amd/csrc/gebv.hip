@@ -58,17 +58,13 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
 
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
-#ifndef BH_GEBV_BITS_WGS  // tuning experiments only: workgroups the K slicing aims at
-#define BH_GEBV_BITS_WGS 512
-#endif
+constexpr int kGebvBitsWgs = 512;  // workgroups the K slicing aims at
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
-#ifndef BH_GEBV_BITS_F  // tuning experiments only: 32-row tiles per wave
-#define BH_GEBV_BITS_F 1
-#endif
-  constexpr int F = BH_GEBV_BITS_F;
+constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
+  constexpr int F = kGebvBitsF;
   const int64_t row_groups = (rows + 128 * F - 1) / (128 * F), rows_pad = row_groups * 128 * F;
-  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((BH_GEBV_BITS_WGS + row_groups - 1) / row_groups, c->n_mc));
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((kGebvBitsWgs + row_groups - 1) / row_groups, c->n_mc));
   const int64_t per_slice = (c->n_mc + slices - 1) / slices;
   slices = (c->n_mc + per_slice - 1) / per_slice;
   const int64_t need = slices * rows_pad * bh::kGebvCols;

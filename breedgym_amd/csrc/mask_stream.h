@@ -44,7 +44,7 @@ __device__ __forceinline__ void mask_stream_role(const MaskParams &p, const int 
   int u = __builtin_amdgcn_readfirstlane(wid * per);
   const int u_end = __builtin_amdgcn_readfirstlane(min(total, u + per));
   if (u >= u_end) return;
-  if constexpr (BH_MASK_PRIO > 0) __builtin_amdgcn_s_setprio(BH_MASK_PRIO);
+  if constexpr (kMaskPrio > 0) __builtin_amdgcn_s_setprio(kMaskPrio);
 
   const scalar_u32_ptr thrA = (scalar_u32_ptr)(uintptr_t)p.thrA, thrB = (scalar_u32_ptr)(uintptr_t)p.thrB;
   const uint32_t M = (uint32_t)p.M, half = (uint32_t)p.half;
@@ -135,11 +135,7 @@ __device__ __forceinline__ void mask_stream_role(const MaskParams &p, const int 
       sA |= ((scalar_u64_ptr)(uintptr_t)p.alwA)[t];
       sB |= ((scalar_u64_ptr)(uintptr_t)p.alwB)[t];
     }
-#if defined(BH_ABLATE_MASK_NOSTORE)  // timing experiments only
-    if (valid && sA == 0x123456789ull) {
-#else
     if (valid) {
-#endif
       // four planes per cross -- A and B words of gamete 0, of gamete 1 -- each spitch words long, so that
       // mask_finish_kernel reads consecutive trips from consecutive words
       uint64_t *Sc = p.sites + (int64_t)c * 4 * p.spitch + t;
@@ -158,6 +154,94 @@ __device__ __forceinline__ void mask_stream_role(const MaskParams &p, const int 
 }
 
 #undef BH_SITE
+
+// ---- rows beyond what one workgroup's LDS holds (more than 2^18 markers) -------------------------------------
+// mask_role keeps a cross's site words in LDS between its two phases: M / 4 bytes, 64 KB at 2^18 markers.  Longer
+// rows (the reference's own cross timing uses 1,406,757 markers, scripts/time_cross.py:14) take the two phases as
+// two kernels with the site words in memory, like the stream-per-lane role above -- but with mask_role's mapping,
+// a LANE per marker pair and any number of waves per cross, because such calls have few crosses (hundreds, not
+// thousands: 64 gamete streams per wave would leave most of the chip idle).  The marker axis is cut into tiles of
+// 64 trips (4096 pairs) per workgroup; the prefix-XOR that runs along the whole row is mask_finish_kernel's, whose
+// carry between its 64-word blocks is the one bit per gamete that has to cross a tile boundary.
+constexpr int kSiteTileTrips = 64;  // trips of 64 marker pairs per workgroup (16 per wave)
+
+__global__ __launch_bounds__(256) void mask_sites_kernel(const MaskParams p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tiles = (p.nwh + kSiteTileTrips - 1) / kSiteTileTrips;
+  const int c = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - c * tiles;
+  if (c >= p.n_rows) return;
+  // gamete keys as in mask_role: lanes 0..3 carry the four words of the two recombination keys
+  uint32_t rk00, rk01, rk10, rk11;
+  {
+    const uint32_t q = (lane >> 1) & 1u, w = lane & 1u;
+    const uint32_t cg = p.key_offset + (uint32_t)c;
+    const uint32_t kidx = p.dh ? 1u + cg : 1u + 2u * cg + q;
+    uint32_t rw;
+    if (p.layout == LAYOUT_PARTITIONABLE) {
+      const u32x2 gk = threefry2x32(p.key0, p.key1, 0u, kidx);
+      const u32x2 rk = threefry2x32(gk.x, gk.y, 0u, 0u);
+      rw = w ? rk.y : rk.x;
+    } else {
+      const uint32_t gw = iota_word_even(p.key0, p.key1, 2u * p.nkeys, 2u * kidx + w);
+      const uint32_t g0 = __shfl(gw, lane & ~1), g1 = __shfl(gw, lane | 1);
+      rw = threefry2x32(g0, g1, w, w + 2u).x;
+    }
+    rk00 = __builtin_amdgcn_readlane(rw, 0);
+    rk01 = __builtin_amdgcn_readlane(rw, 1);
+    rk10 = __builtin_amdgcn_readlane(rw, 2);
+    rk11 = __builtin_amdgcn_readlane(rw, 3);
+  }
+  const KeySched ka = key_sched(rk00, rk01), kb = key_sched(rk10, rk11);
+  uint64_t *S = p.sites + (int64_t)c * 4 * p.spitch;
+  const int t_end = min(p.nwh, (tile + 1) * kSiteTileTrips);
+  for (int t = tile * kSiteTileTrips + wv; t < t_end; t += 4) {
+    const uint32_t j = (uint32_t)t * 64u + (uint32_t)lane;
+    const uint32_t tA = p.thrA[j], tB = p.thrB[j], c1 = p.ctrB[j];  // tables are padded past the last pair
+    uint64_t sA0, sB0, sA1, sB1;
+    if (p.layout == LAYOUT_PARTITIONABLE) {  // marker m draws o0 ^ o1 of TF(key, (0, m)): pairs [0, half), then [half, M)
+      uint32_t a0 = rk00, a1 = j + rk01, b0 = rk10, b1 = j + rk11;
+      asm volatile(BH_TFA BH_TFB
+                   : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]), "s"(ka.w[6]),
+                     "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]), "s"(kb.w[4]), "s"(kb.w[5]),
+                     "s"(kb.w[6]), "s"(kb.w[7]));
+      uint32_t c0 = rk00, c1v = c1 + rk01, d0 = rk10, d1 = c1 + rk11;
+      asm volatile(BH_TFA BH_TFB
+                   : "+v"(c0), "+v"(c1v), "+v"(d0), "+v"(d1)
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]), "s"(ka.w[6]),
+                     "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]), "s"(kb.w[4]), "s"(kb.w[5]),
+                     "s"(kb.w[6]), "s"(kb.w[7]));
+      sA0 = __ballot((a0 ^ a1) < tA);
+      sB0 = __ballot((c0 ^ c1v) < tB);
+      sA1 = __ballot((b0 ^ b1) < tA);
+      sB1 = __ballot((d0 ^ d1) < tB);
+    } else {  // pair j draws marker j (word 0) and marker j + half (word 1) of TF(key, (j, j + half))
+      uint32_t a0 = j + rk00, a1 = c1 + rk01, b0 = j + rk10, b1 = c1 + rk11;
+      asm volatile(BH_TFA BH_TFB
+                   : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]), "s"(ka.w[6]),
+                     "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]), "s"(kb.w[4]), "s"(kb.w[5]),
+                     "s"(kb.w[6]), "s"(kb.w[7]));
+      sA0 = __ballot(a0 < tA);
+      sB0 = __ballot(a1 < tB);
+      sA1 = __ballot(b0 < tA);
+      sB1 = __ballot(b1 < tB);
+    }
+    if (p.alwA) {  // markers with r >= 1: always a site
+      const uint64_t xa = p.alwA[t], xb = p.alwB[t];
+      sA0 |= xa;
+      sA1 |= xa;
+      sB0 |= xb;
+      sB1 |= xb;
+    }
+    if (lane == 0) {  // the planes mask_finish_kernel reads: A and B words of gamete 0, then of gamete 1
+      S[t] = sA0;
+      S[p.spitch + t] = sB0;
+      S[2 * (int64_t)p.spitch + t] = sA1;
+      S[3 * (int64_t)p.spitch + t] = sB1;
+    }
+  }
+}
 
 // site_word (row_kernels.h) for the planar site array of one cross: the 64 site bits of markers [64w, 64w + 64) of
 // gamete g; plane 2g holds the A words (markers [0, half) from bit 0 of word 0), plane 2g + 1 the B words

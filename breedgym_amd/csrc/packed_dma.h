@@ -26,10 +26,7 @@
 
 namespace bh {
 
-#ifndef BH_DMA_SLOTS  // chunks in flight per row wave (tuning experiments only)
-#define BH_DMA_SLOTS 6
-#endif
-constexpr int kDmaSlots = BH_DMA_SLOTS;
+constexpr int kDmaSlots = 6;  // chunks in flight per row wave
 constexpr int kDmaSlotBytes = 3 * 1024;                   // parent 0 | parent 1 | mask, 512 words each (a gather: 1 KB)
 constexpr int kDmaRingBytes = kDmaSlots * kDmaSlotBytes;  // per row wave of a cross
 constexpr int kDmaGatherRingBytes = kDmaSlots * 1024;     // per row wave of a gather
@@ -78,15 +75,11 @@ __device__ __forceinline__ void dma_read128(uint32_t addr, uint4 &a) {
 // The byte-layout observation of long rows is written once and not read again by the launches that follow (1.6 GB
 // at 8192 x 100k, far beyond the 256 MB Infinity Cache): as a non-temporal stream it leaves the cache to the bit-plane
 // offspring, which the GEBV pass and the next launch's parent reads want (configs[2]: launch 0.628 -> 0.592 ms, GEBV
-// pass 90 -> 81 us; BH_DMA_OBS_TEMPORAL switches it off for experiments).
+// pass 90 -> 81 us).
 __device__ __forceinline__ void store_obs(char *dst, const uint4 v) {
-#if defined(BH_DMA_OBS_TEMPORAL)
-  *reinterpret_cast<uint4 *>(dst) = v;
-#else
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 x = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(dst));
-#endif
 }
 
 // cross16 on two packed words at once (no bit crosses a marker, let alone a word)
@@ -113,7 +106,7 @@ __device__ __forceinline__ void packed_dma_role(const PackedParams &p, const int
   typedef const int32_t __attribute__((address_space(4))) *scalar_i32_ptr;
   const int lane = threadIdx.x & 63;
   const int seq = p.seq > 1 ? p.seq : 1;
-  __builtin_amdgcn_s_setprio(BH_LONG_ROW_PRIO);
+  __builtin_amdgcn_s_setprio(kLongRowPrio);
   const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * seq);
   if (first >= p.n_rows) return;
   const int rows_here = p.n_rows - first < seq ? p.n_rows - first : seq;

@@ -20,17 +20,9 @@
 
 namespace bh {
 
-#ifndef BH_LONG_ROW_PRIO  // priority of the row waves of the long-row stream (tuning experiments only)
-#define BH_LONG_ROW_PRIO 2
-#endif
-#ifndef BH_LONG_VPT  // vectors per lane and trip in the long-row stream (tuning experiments only)
-#define BH_LONG_VPT 4
-#endif
-constexpr int kLongRowVectors = BH_LONG_VPT;
-#ifndef BH_SHORT_VPT  // ... and in the stream with GEBV (tuning experiments only)
-#define BH_SHORT_VPT 2
-#endif
-constexpr int kShortRowVectors = BH_SHORT_VPT;
+constexpr int kLongRowPrio = 2;  // priority of the row waves of the long-row stream
+constexpr int kLongRowVectors = 4;   // vectors per lane and trip in the long-row stream
+constexpr int kShortRowVectors = 2;  // ... and in the stream with GEBV
 
 struct PackedParams {
   const uint16_t *src;  // cross: (E, n_pool, nvp) packed pool; gather: (n_pool, nvp)
@@ -226,7 +218,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   const int seq = p.seq > 1 ? p.seq : 1;
   // without GEBV the stream is almost all memory instructions: above the mask waves it keeps the memory pipeline
   // fed and they take every issue slot it leaves (their role has no vector loads to be starved of, mask_stream.h)
-  if constexpr (TT == 0) __builtin_amdgcn_s_setprio(BH_LONG_ROW_PRIO);
+  if constexpr (TT == 0) __builtin_amdgcn_s_setprio(kLongRowPrio);
   const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R * seq);
   for (int sq = 0; sq < seq; ++sq) {
     const int c0 = first + sq * R;
@@ -288,12 +280,6 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         v = v < last ? v : last;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-#if defined(BH_ABLATE_NO_LOADS)  // timing experiments only: the stream's stores without its loads
-          w.a[u][r] = (uint32_t)v * 2654435761u >> 16;
-          w.b[u][r] = (uint32_t)v * 40503u & 0xffffu;
-          w.z[u][r] = (uint32_t)v * 9973u & 0xffffu;
-          continue;
-#endif
           w.a[u][r] = word_at(src0[r], (uint32_t)v);
           if constexpr (MODE == MODE_CROSS) {
             w.b[u][r] = word_at(src1[r], (uint32_t)v);
@@ -305,13 +291,9 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         }
       }
     };
-#ifndef BH_LONG_AHEAD  // trips the stream requests ahead: without / with GEBV (tuning experiments only)
-#define BH_LONG_AHEAD 1
-#endif
-#ifndef BH_SHORT_AHEAD
-#define BH_SHORT_AHEAD 1
-#endif
-    constexpr int AHEAD = TT == 0 ? BH_LONG_AHEAD : BH_SHORT_AHEAD;
+constexpr int kLongAhead = 1;  // trips the stream requests ahead: without / with GEBV
+constexpr int kShortAhead = 1;
+    constexpr int AHEAD = TT == 0 ? kLongAhead : kShortAhead;
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
       uint4 dg[VPT][NT][3];
@@ -321,21 +303,10 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           const int vu = v + 64 * u < last ? v + 64 * u : last;
 #pragma unroll
           for (int q = 0; q < TT; ++q) {
-#if defined(BH_DIG_INTERLEAVED)  // tuning experiments only: digits of a vector side by side (lane stride 48 B)
-            const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vu) * 3;
-            dg[u][q][0] = dp[0];
-            dg[u][q][1] = dp[1];
-            dg[u][q][2] = dp[2];
-#elif defined(BH_ABLATE_NO_DIGITS)  // timing experiments only: the stream without its effect-digit loads
-            dg[u][q][0] = make_uint4(vu, 1, 2, 3);
-            dg[u][q][1] = make_uint4(3, vu, 2, 1);
-            dg[u][q][2] = make_uint4(1, 2, vu, 3);
-#else  // one plane per digit: a wave's load is 1 KB contiguous
             const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vu;
             dg[u][q][0] = dp[0];
             dg[u][q][1] = dp[p.nvec];
             dg[u][q][2] = dp[2 * (int64_t)p.nvec];
-#endif
           }
         }
       }
@@ -348,14 +319,9 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           const int vu = v + 64 * u < last ? v + 64 * u : last;
           uint32_t o = w.a[u][r];
           if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
-#if defined(BH_ABLATE_NO_STORES)  // timing experiments only: the stream's loads without its stores
-          if (o == 0x12345u) *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
-          const uint4 oo = expand_vector(o);
-#else
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
           const uint4 oo = expand_vector(o);
           if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo;
-#endif
           if constexpr (TT > 0) {
             if (has) {  // a lane that redid the last vector must not count it twice
               typedef short short2v __attribute__((ext_vector_type(2)));
@@ -440,7 +406,6 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
     __syncthreads();
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
-#if !defined(BH_LONG_NO_DMA)
   if constexpr (TT == 0 && R == 1) {
     // long rows in turns (the founder gather of a reset, a cross without run-ahead): the LDS-DMA stream
     if (p.outp && p.seq > 1) {
@@ -452,7 +417,6 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
       return;
     }
   }
-#endif
   if constexpr (TT <= 2) {
     // packed rows out (reset's founder gather, a cross without run-ahead): the pipelined stream; without
     // GEBV only where the host asks for it (p.seq > 1: long rows in turns)
@@ -496,14 +460,8 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     }
     __syncthreads();
   }
-#if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation_packed.sh)
-  if (wave < 4) return;
-#elif defined(BH_ABLATE_NO_MASKROLE)
-  if (wave >= 4) return;
-#endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) {
-#if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
           if (rp.outb)
@@ -513,7 +471,6 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
           return;
         }
       }
-#endif
       packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, &rwl);
     }
   } else if constexpr (MW == 1) {
@@ -539,27 +496,13 @@ template <int R, int MASK_WAVES>
 __global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(const PackedParams rp, const MaskParams mp) {
   prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#if !defined(BH_LONG_NO_DMA)
   static_assert(R == 1, "the LDS-DMA stream takes one row per turn");
   __shared__ __attribute__((aligned(16))) char ring[4][kDmaRingBytes];  // one ring per row wave (packed_dma.h)
-#endif
-#if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only
-  if (wave < 4) return;
-#elif defined(BH_ABLATE_NO_MASKROLE)
-  if (wave >= 4) return;
-#endif
   if (wave < 4) {
-#if !defined(BH_LONG_NO_DMA)
     if (rp.outb)
       packed_dma_role<MODE_CROSS, true>(rp, (int)blockIdx.x, wave, ring[wave]);
     else
       packed_dma_role<MODE_CROSS, false>(rp, (int)blockIdx.x, wave, ring[wave]);
-#else  // tuning experiments only: the register-staged stream
-    if (rp.outb)
-      packed_stream_role<0, MODE_CROSS, R, true, kLongRowVectors>(rp, (int)blockIdx.x, wave);
-    else
-      packed_stream_role<0, MODE_CROSS, R, false, kLongRowVectors>(rp, (int)blockIdx.x, wave);
-#endif
   } else {
     mask_stream_role(mp, (int)blockIdx.x * MASK_WAVES + wave - 4, (int)gridDim.x * MASK_WAVES);
   }

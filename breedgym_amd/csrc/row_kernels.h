@@ -30,9 +30,7 @@
 
 #include "threefry.h"
 
-#ifndef BH_MASK_PRIO  // priority of mask waves next to row waves (tuning experiments only)
-#define BH_MASK_PRIO 1
-#endif
+constexpr int kMaskPrio = 1;  // priority of mask waves next to row waves
 
 namespace bh {
 
@@ -271,7 +269,7 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
   // four-wave groups run next to row waves at the default priority (few keyed crosses, the launch
   // is bound by the streaming): one step above them the mask role is out of the way sooner --
   // 1-5 % on most shapes, 11 % at 2200 x 16k markers, -2 % on one (profiles/r01_ab_mask_priority.txt)
-  if constexpr (SYNC == SYNC_COUNTER && BH_MASK_PRIO > 0) __builtin_amdgcn_s_setprio(BH_MASK_PRIO);
+  if constexpr (SYNC == SYNC_COUNTER && kMaskPrio > 0) __builtin_amdgcn_s_setprio(kMaskPrio);
   uint64_t *S = reinterpret_cast<uint64_t *>(lds_raw + (size_t)grp * p.group_lds);  // [nwh + 1][4]
 
   // ---- gamete keys: keys = split(sim_key, nkeys); gamete (c, q) owns keys[1 + 2c + q] (double
@@ -384,15 +382,9 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     }                                                                                                               \
   }
 
-#if defined(BH_ABLATE_MASK_NOLOAD)  // timing experiments only: the mask role without its table loads (wrong masks)
-#define BH_TLOAD(r_, v_, s_) ((v_) + (s_))
-#else
 #define BH_TLOAD(r_, v_, s_) __builtin_amdgcn_raw_buffer_load_b32(r_, v_, s_, 0)
-#endif
-#ifndef BH_MASK_NPF  // trips whose tables are requested ahead (tuning experiments only)
-#define BH_MASK_NPF 4
-#endif
-  constexpr int NPF = BH_MASK_NPF;
+constexpr int kMaskNpf = 4;  // trips whose tables are requested ahead
+  constexpr int NPF = kMaskNpf;
   if (p.layout == LAYOUT_PARTITIONABLE)
   {
     int t = wv;
@@ -596,11 +588,7 @@ __device__ __forceinline__ void row_role(const RowParams &p, const int block, co
   // NC independent chains per sum.  Long rows (HBM-resident sets, few waves per SIMD doing the sums)
   // gain 8 % from four chains -- a single chain of dependent f64 FMAs waits out the FMA latency
   // eight times per vector; 10k-marker rows lose 2 % to the extra registers (tools/run_ab_chains.sh).
-#if defined(BH_GEBV_CHAINS)  // tuning experiments only
-  constexpr int NC = BH_GEBV_CHAINS;
-#else
   constexpr int NC = !LONG ? 1 : (NT * R <= 4 ? 4 : (NT * R <= 8 ? 2 : 1));
-#endif
   double acc[R][NT][NC];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -787,17 +775,10 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
     uint4 dg[TT][3];
 #pragma unroll
     for (int q = 0; q < TT; ++q) {
-#if defined(BH_DIG_INTERLEAVED)  // tuning experiments only: digits of a vector side by side (lane stride 48 B)
-      const uint4 *dp = p.dig + ((int64_t)(p.t0 + q) * p.nvec + vv) * 3;
-      dg[q][0] = dp[0];
-      dg[q][1] = dp[1];
-      dg[q][2] = dp[2];
-#else  // one plane per digit: a wave's load is 1 KB contiguous
       const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vv;
       dg[q][0] = dp[0];
       dg[q][1] = dp[p.nvec];
       dg[q][2] = dp[2 * (int64_t)p.nvec];
-#endif
     }
     load_vecs(base + 64, next);
     uint4 oo[R];
@@ -904,18 +885,11 @@ __global__ __launch_bounds__(512) void cross_kernel(const RowParams rp, const Ma
     }
     __syncthreads();
   }
-#if defined(BH_ABLATE_NO_ROWROLE)  // timing experiments only (tools/run_ablation.sh)
-  if (wave < 4) return;
-#elif defined(BH_ABLATE_NO_MASKROLE)
-  if (wave >= 4) return;
-#endif
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) {
-#if !defined(BH_ROW_PLAIN)  // BH_ROW_PLAIN: tuning experiments only
       if constexpr ((TT == 1 || TT == 2) && !LONG && MW == 4)
         row_role_pipelined<TT, R>(rp, (int)blockIdx.x, wave, &rwl);
       else
-#endif
         row_role<1, TT, MODE_CROSS, R, LONG, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, nullptr, &rwl);
     }
   } else if constexpr (MW == 1) {

@@ -85,7 +85,8 @@ int bh_sync(bh_ctx *ctx);
 int64_t bh_row_pitch(const bh_ctx *ctx);
 int64_t bh_n_markers(const bh_ctx *ctx);
 int64_t bh_n_traits(const bh_ctx *ctx);
-/* largest marker count the LDS-staged crossover masks allow */
+/* largest marker count a context takes (2^22; the reference's largest shape, scripts/time_cross.py:14, has
+ * 1,406,757 markers) */
 int64_t bh_max_markers(void);
 
 /* ---- device memory for callers without a HIP runtime of their own ------------------ */

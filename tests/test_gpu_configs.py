@@ -621,3 +621,53 @@ def test_c1_single_env_at_shape():
                 assert rew == 0
             else:
                 assert abs(rew - g64.mean()) <= 1e-5 * max(1.0, abs(g64.mean()))
+
+
+# ---- rows beyond one workgroup's LDS: site words through memory (csrc/mask_stream.h, mask_sites_kernel) ----------
+
+
+@pytest.mark.parametrize("layout,M,C,mode", [("original", 1_406_757, 300, 1), ("partitionable", 1_406_757, 64, 0),
+                                              ("original", 262_145, 500, 1), ("original", 300_001, 130, 3)])
+def test_rows_beyond_the_lds_mask_limit(layout, M, C, mode, rng):
+    """The reference's own cross timing shape (scripts/time_cross.py:11-14: 300 progenies x 1,406,757 markers) and
+    rows just past 2^18 markers: every offspring byte of two calls against the oracle, bit planes and byte layout,
+    GEBV within 1e-5 -- the prefix-XOR of a row runs over site words in memory with the crossover parity carried
+    from tile to tile."""
+    from breedgym_amd import HipEngine, _lib
+
+    assert _lib.lib().bh_max_markers() >= 1 << 21
+    co.set_threefry_layout(layout)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    try:
+        NP = 24
+        pool = rng.integers(0, 2, (1, NP, M, 2), dtype=np.uint8)
+        r = (rng.random(M) * 0.0004).astype(np.float32)
+        r[:: M // 21] = 0.5
+        r[rng.random(M) < 0.16] = 0.0
+        r[7], r[M // 2 + 1], r[M - 1] = 1.0, 1.5, 1.0
+        eff = rng.laplace(0, 6, (M, 1)).astype(np.float32)
+        eng = HipEngine(r, eff, threefry_layout=layout)
+        if mode & 2:
+            one = rng.integers(0, NP, (1, C), dtype=np.int32)
+            idx = np.stack((one, one), -1)
+        else:
+            idx = rng.integers(0, NP, (1, C, 2), dtype=np.int32)
+        d_idx = torch.from_numpy(idx).to(eng.device)
+        rows = eng.upload_population(pool[0])
+        packed = eng.pack(rows)
+        key_p, key_b, ref_key = co.key_from_seed(5).copy(), co.key_from_seed(5).copy(), co.key_from_seed(5)
+        for call in range(2):
+            ref, ref_key = co.cross(pool, idx, r, ref_key, mode)
+            g64 = co.gebv(ref, eff, want64=True)[1]
+            outp, ob, g = eng.empty_packed(C), eng.empty_population(C), eng.empty((1, C, 1), torch.float32)
+            eng.cross_packed(packed, 1, NP, d_idx, C, key_p, mode, outp, ob, g)
+            assert np.array_equal(eng.download_population(ob).view(np.uint8).reshape(ref.shape), ref), f"packed, call {call}"
+            assert torch.equal(eng.unpack(outp), ob)
+            assert np.array_equal(key_p, ref_key) and gebv_close(g.cpu().numpy(), g64)
+            if call == 0:  # the byte-layout state takes the same masks through its own row kernel
+                out, g2 = eng.empty_population(C), eng.empty((1, C, 1), torch.float32)
+                eng.cross(rows, 1, NP, d_idx, C, key_b, mode, out, g2)
+                assert torch.equal(out, ob) and np.array_equal(key_b, ref_key) and gebv_close(g2.cpu().numpy(), g64)
+        eng.sync()
+    finally:
+        co.set_threefry_layout("original")
