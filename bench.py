@@ -170,6 +170,12 @@ def time_cross_launches(env, actions, reps, with_gebv=True):
 
 def roofline_of(kernel, nbytes, ms, **extra):
     achieved = nbytes / (ms * 1e-3) / 1e9
+    if extra.get("traffic") is not None:
+        # what the counters are (MI355X_MICROARCH.md, HBM section): requests at the memory side of the L2, Infinity-Cache
+        # hits included -- an upper bound on HBM bytes, not HBM bytes; the 2 x on FETCH_SIZE is calibrated for the
+        # 16-byte-per-lane streaming reads these kernels issue (LDS-DMA and global_load alike)
+        extra.setdefault("traffic_is", "memory-side (fabric) bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits "
+                                       "are counted, so at cache-resident sizes this is an upper bound on HBM bytes")
     return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "bytes_per_launch": nbytes, "kernel_ms": ms, **extra}
 
@@ -233,8 +239,18 @@ def live_traffic(timeout=90):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", f"{tmp}/{ctr}", "-o", "p", "--",
                    sys.executable, str(ROOT / "bench.py"), "--traffic-child"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=timeout)
+            # own process group: on a timeout the profiler AND the python child under it are ended, so that nothing of
+            # them overlaps the timed region
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, 9)
+                proc.wait()
+                _LIVE_NOTE = f"rocprofv3 --pmc {ctr} pass timed out after {timeout} s"
+                return
+            r = proc
             files = glob.glob(f"{tmp}/{ctr}/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 _LIVE_NOTE = f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode})"
@@ -358,8 +374,9 @@ def bench_c5(reps):
     }
 
 
-def bench_population(args, rank, world, local_rank, use_dist, barrier):
-    """BASELINE configs[3]: one population sharded row-wise, 8192 x 100k per rank, k = n_total // 10."""
+def population_generation(steps, warmup, rank, world, local_rank, use_dist, barrier):
+    """BASELINE configs[3]: one population sharded row-wise, 8192 x 100k per rank, k = n_total // 10.  Returns the
+    JSON line of the population mode (rank 0; None elsewhere)."""
     import torch
     import torch.distributed as dist
 
@@ -369,7 +386,7 @@ def bench_population(args, rank, world, local_rank, use_dist, barrier):
 
     n_local, M = 8192, 100_000
     n_total = n_local * world
-    k = min(n_total // 10, 16384)
+    k = n_total // 10
     gm = synthetic_genetic_map(M, n_chr=21, n_traits=1, seed=1)
     sim = Simulator(genetic_map=gm, seed=5, device=local_rank)
     eng = sim.engine
@@ -387,11 +404,11 @@ def bench_population(args, rank, world, local_rank, use_dist, barrier):
     mine = slice(rank * n_local, (rank + 1) * n_local)
     pairs = [torch.from_numpy(prng.integers(0, k, (n_total, 2), dtype=np.int32)[mine].copy()).to(eng.device) for _ in range(2)]
     key = np.array([0, 5], np.uint32)
-    for i in range(args.warmup):
+    for i in range(warmup):
         sp.select_and_cross(k, pairs[i % 2], key)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         sp.select_and_cross(k, pairs[i % 2], key)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -400,22 +417,58 @@ def bench_population(args, rank, world, local_rank, use_dist, barrier):
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    if rank == 0:
-        pp = packed_pitch(M)
-        line = {
-            "metric": "crosses/sec (population-sharded generation: top-k GEBV selection + crosses) at 8192 x 100k markers per GPU",
-            "value": world * args.steps * n_local / dt_max, "unit": "crosses/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {
-                "workload": f"BASELINE configs[3]: {n_total} individuals x 100k markers over {world} GPU(s), 8192 per rank, "
-                            f"top-{k} by GEBV, every rank crosses its shard from the replicated winners",
-                "n_markers": M, "crosses_per_step_per_gpu": n_local, "storage": "bits",
-                "collectives": f"all-gather of {min(k, n_local)} (score, index) candidates per rank; one all-reduce of the "
-                               f"winners' bit-plane rows ({k * pp / 1e6:.0f} MB buffer, each row filled by its owner)",
-            },
-        }
+    if rank != 0:
+        return None
+    pp = packed_pitch(M)
+    return {
+        "metric": "crosses/sec (population-sharded generation: top-k GEBV selection + crosses) at 8192 x 100k markers per GPU",
+        "value": world * steps * n_local / dt_max, "unit": "crosses/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[3]: {n_total} individuals x 100k markers over {world} GPU(s), 8192 per rank, "
+                        f"top-{k} by GEBV, every rank crosses its shard from the replicated winners",
+            "n_markers": M, "crosses_per_step_per_gpu": n_local, "storage": "bits",
+            "collectives": f"all-gather of {min(k, n_local)} (score, index) candidates per rank; one all-gather of the "
+                           f"winners' bit-plane rows, every rank sending the rows it owns padded to the largest share "
+                           f"({k * pp / 1e6:.0f} MB of rows in all)",
+        },
+        "bytes_per_generation_per_gpu": {"shard_read_for_gebv": n_local * pp, "winner_rows_gathered": k * pp,
+                                         "parents_read": 2 * n_local * pp, "offspring_written": n_local * pp,
+                                         "masks_written_and_read": 2 * n_local * pp},
+        "bound": "VALU: every cross owns its keys (one flat chromax batch), 2 gametes x 50k Threefry-2x32-20 calls each -- "
+                 "JAX's bit stream itself; the bit-plane traffic above is ~0.05 of what HBM moves in that time",
+    }
+
+
+def bench_population(args, rank, world, local_rank, use_dist, barrier):
+    line = population_generation(args.steps, args.warmup, rank, world, local_rank, use_dist, barrier)
+    if line is not None:
         print(json.dumps(line), flush=True)
+
+
+def bench_c4_one_rank(steps, warmup, barrier):
+    """BASELINE configs[3] as far as one GPU goes: one rank's generation (8192 x 100k shard, its own top-k), and the
+    action shaping of the whole 65,536-individual population (`SelectionScores` with the reference's default
+    k = n // 10: 21.5 M diallel pairs shuffled by three rounds of radix sorts in HBM)."""
+    import torch
+
+    from breedgym_amd import HipEngine
+
+    line = population_generation(steps, warmup, 0, 1, torch.cuda.current_device(), False, barrier)
+    out = {"workload": line["config"]["workload"], "ms_per_generation": line["ms_per_step"], "value": line["value"],
+           "unit": line["unit"], "bytes_per_generation": line["bytes_per_generation_per_gpu"], "bound": line["bound"],
+           "note": "ONE rank's share, measured on one GPU; the 8-rank run (bench.py --gpus 8 --mode population) adds the two "
+                   "all-gathers over RCCL, which no 1-GPU run can time"}
+    eng = HipEngine(np.full(64, 0.01, np.float32), np.ones((64, 1), np.float32))
+    n, k, nc = 65_536, 6_553, 8_192
+    scores = torch.randn((1, n), device=eng.device)
+    key = np.array([0, 9], np.uint32)
+    ms = time_events(lambda i: eng.selection_actions(scores, k, nc, key), max(5, steps // 4), warm=2)
+    out["selection_actions"] = {"shape": f"n = {n}, k = {k} (n // 10), {k * (k - 1) // 2} pairs, n_crosses = {nc}", "ms": ms,
+                                "note": "bh_selection_actions: top-k by radix select, 3 shuffle rounds x 4 radix passes over "
+                                        "(key, value) pairs in HBM, un-ranking"}
+    return out
 
 
 def main():
@@ -428,7 +481,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline configuration: no CPU leg, no other key mode / storage / config lines "
                          "(profiling runs, so that a kernel name in the profile is one configuration)")
-    ap.add_argument("--only", choices=("c3", "c3lazy", "c5"), default=None,
+    ap.add_argument("--only", choices=("c3", "c3lazy", "c5", "c4"), default=None,
                     help="run only that extra configuration (profiling runs: one configuration per kernel name)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the rocprofv3 --pmc child passes behind roofline.traffic (committed passes are named instead)")
@@ -491,6 +544,9 @@ def main():
         return
     if args.only == "c5":
         print(json.dumps({"configs": {"c5": bench_c5(max(20, args.steps // 4))}}))
+        return
+    if args.only == "c4":
+        print(json.dumps({"configs": {"c4_one_rank": bench_c4_one_rank(max(10, args.steps // 10), max(3, args.warmup // 10), barrier)}}))
         return
 
     gm = synthetic_genetic_map(N_MARKERS, n_chr=10, n_traits=1, seed=1)
@@ -617,7 +673,8 @@ def main():
             del env
             torch.cuda.empty_cache()
             line["configs"] = {"c3": bench_c3(max(10, args.steps // 10), max(3, args.warmup // 10), barrier),
-                               "c5": bench_c5(max(20, args.steps // 4))}
+                               "c5": bench_c5(max(20, args.steps // 4)),
+                               "c4_one_rank": bench_c4_one_rank(max(10, args.steps // 10), max(3, args.warmup // 10), barrier)}
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline(gm, geno, 0)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

@@ -103,6 +103,11 @@ struct bh_ctx {
   // reward chaining (bh_cross*): the buffer the last launch left holding -inf, ready to take atomic maxima
   const float *primed_reward = nullptr;
   int64_t primed_envs = 0, primed_pitch = 0;
+  // bh_step_bind: the caller's ring of output blocks for bh_step
+  struct {
+    int64_t n_envs = 0, n_out = 0, depth = 0, reward_pitch = 1;
+    std::vector<void *> state, obs, gebv, reward;
+  } ring;
   bool big_lds_set = false;
   bool select_lds_set = false;
   // device-side error word: host memory the kernels can write (a hand-off wait that ran out, row_kernels.h)

@@ -91,6 +91,67 @@ class PackedPopulation:
         return self.unpack()[item]
 
 
+class StepRing:
+    """The output blocks of ``VecBreedGym.step``, allocated once and reused in turn (include/breedhip.h, bh_step_bind).
+
+    Slot s holds a generation: bit-plane state, byte-layout observation (unless the env hands out lazy ones), GEBV
+    and reward, each with the Python views the env returns already made.  ``step`` is the whole host side of a
+    generation: pick the next slot, one ``bh_step`` call.  What a slot held ``depth`` steps ago is overwritten --
+    an observation stays valid for ``depth - 1`` further steps / resets."""
+
+    OBS, REWARD = 4, 8  # bh_step flags
+
+    def __init__(self, eng, n_envs, n_out, depth, with_observations):
+        if depth < 2:
+            raise ValueError("a step ring needs at least two slots")
+        self.eng, self.n_envs, self.n_out, self.depth = eng, int(n_envs), int(n_out), int(depth)
+        rows, dev = self.n_envs * self.n_out, eng.device
+        self.state = [torch.empty((rows, eng.packed_pitch), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.obs_rows = [torch.empty((rows, eng.pitch), dtype=torch.uint8, device=dev) if with_observations else None
+                         for _ in range(depth)]
+        self.gebv = [torch.empty((n_envs, n_out, eng.n_traits), dtype=torch.float32, device=dev).as_subclass(DeviceArray)
+                     for _ in range(depth)]
+        self.reward = [torch.empty_strided((n_envs,), (64,), dtype=torch.float32, device=dev).as_subclass(DeviceArray)
+                       for _ in range(depth)]
+        # what the env hands out, made once
+        self.populations = [None if r is None else eng.as_genotypes(r, n_envs, n_out) for r in self.obs_rows]
+        self.lazy = [PackedPopulation(eng, st, (n_envs, n_out)) for st in self.state]
+        self.state_ptr = [t.data_ptr() for t in self.state]
+        self.cursor = depth - 1  # the slot written last
+
+        def table(ts):
+            return (ctypes.c_void_p * depth)(*[t.data_ptr() for t in ts])
+
+        _lib.check(eng._L.bh_step_bind(
+            eng._h, self.n_envs, self.n_out, depth, table(self.state), table(self.obs_rows) if with_observations else None,
+            table(self.gebv), table(self.reward), 64))
+        self._bh_step, self._h = eng._L.bh_step, eng._h
+        self._key_obj = self._key_ptr = None
+
+    def take(self) -> int:
+        """Claim the next slot (a reset gathers its founders into it)."""
+        self.cursor = s = (self.cursor + 1) % self.depth
+        self.lazy[s]._bytes = None
+        return s
+
+    def step(self, pool_ptr: int, pool_rows: int, idx: torch.Tensor, key: np.ndarray, flags: int, prime_ahead: int) -> int:
+        """One generation into the next slot; ``prime_ahead`` (0: none) = how many slots ahead the next step that
+        has a reward will write.  Returns the slot."""
+        s = self.take()
+        if key is not self._key_obj:
+            assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
+            self._key_obj, self._key_ptr = key, key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        rc = self._bh_step(self._h, s, (s + prime_ahead) % self.depth if prime_ahead else -1, pool_ptr, pool_rows,
+                           idx.data_ptr(), self._key_ptr, flags)
+        if rc:
+            _lib.check(rc)
+        return s
+
+    def close(self):
+        if self.eng._h:
+            self.eng._L.bh_step_bind(self.eng._h, 0, 0, 0, None, None, None, None, 1)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -314,6 +375,11 @@ class HipEngine(EngineBase):
         if rc:
             _lib.check(rc)
         return outp, out, gebv, nxt
+
+    def step_ring(self, n_envs: int, n_out: int, depth: int, with_observations: bool) -> "StepRing":
+        """``depth`` slots of output blocks for ``VecBreedGym.step``, bound to the context (bh_step_bind): a step
+        then is one C call with no allocation (``StepRing.step``)."""
+        return StepRing(self, n_envs, n_out, depth, with_observations)
 
     def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None) -> None:
         """Rows ``idx`` (or 0..n_rows-1) of packed ``src`` -> packed and/or byte-layout rows and/or GEBV."""

@@ -272,3 +272,42 @@ def test_vec_env_bit_plane_storage(observations, env_rng):
         o0 = w0.step(s)[0]
         o1 = w1.step(s)[0]
         assert np.array_equal(np.asarray(o1), np.asarray(o0))
+
+
+@pytest.mark.parametrize("observations", ["eager", "lazy"])
+def test_step_ring_equals_fresh_blocks(observations, rng):
+    """The default ring of output blocks (ring_depth=4, bh_step) against a fresh block per step (ring_depth=0,
+    bh_cross_packed): same observations, GEBV, rewards and key chains over two episodes incl. the autoreset; and
+    what a step hands out stays intact for ring_depth - 1 further steps."""
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    E, n, N, M, G = 3, 40, 50, 777, 4
+    gm = synthetic_genetic_map(M, n_chr=3, seed=2)
+    geno = synthetic_genotypes(N, M, seed=3)
+    kw = dict(num_envs=E, initial_population=geno, individual_per_gen=n, genetic_map=gm, num_generations=G,
+              reward_shaping=True, sync_rewards=False, observations=observations)
+    ring, fresh = VecBreedGym(ring_depth=4, **kw), VecBreedGym(ring_depth=0, **kw)
+    assert ring.reset(seed=9)[0].shape == fresh.reset(seed=9)[0].shape
+    assert ring._ring is not None and fresh._ring is None
+    held = []  # (step it came from, the handed-out observation, a host copy made at once)
+    for t in range(2 * G + 1):
+        a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
+        o1, r1, _, tr1, i1 = ring.step(a)
+        o2, r2, _, tr2, i2 = fresh.step(a)
+        assert np.array_equal(np.asarray(o1), np.asarray(o2)), t
+        assert np.array_equal(np.asarray(i1["GEBV"]), np.asarray(i2["GEBV"]))
+        assert np.array_equal(np.asarray(r1), np.asarray(r2)) and np.array_equal(tr1, tr2)
+        assert np.array_equal(ring.simulator.random_key, fresh.simulator.random_key)
+        assert np.array_equal(ring.random_key, fresh.random_key)
+        assert np.array_equal(np.asarray(ring.populations), np.asarray(fresh.populations))
+        held.append((t, o1, np.asarray(o1).copy()))
+        for t0, obs, copy in held[-2:]:  # the last two observations are still what they were (a reset may sit between)
+            assert np.array_equal(np.asarray(obs), copy), (t, t0)
+    # a wrapper may replace the populations (breeding_programs_env.py:56): the next step reads them
+    newpop = np.asarray(fresh.populations).copy()[:, ::-1]
+    ring.populations, fresh.populations = newpop, newpop
+    a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
+    assert np.array_equal(np.asarray(ring.step(a)[0]), np.asarray(fresh.step(a)[0]))
+    with pytest.raises(ValueError):
+        VecBreedGym(ring_depth=2, **kw)
