@@ -698,24 +698,28 @@ int bh_cross_packed(bh_ctx *c, const uint16_t *d_pool, int64_t n_envs, int64_t p
 }
 
 int bh_step_bind(bh_ctx *c, int64_t n_envs, int64_t n_out, int64_t depth, void *const *d_state, void *const *d_obs,
-                 void *const *d_gebv, void *const *d_reward, int64_t reward_pitch) {
+                 void *const *d_gebv, int64_t n_rewards, void *const *d_reward, int64_t reward_pitch) {
   if (int rc = check_ctx(c)) return rc;
   if (depth == 0) {  // unbind
     c->ring = {};
     return BH_OK;
   }
-  if (n_envs <= 0 || n_out <= 0 || depth < 2 || depth > 64 || reward_pitch < 1 || !d_state || !d_gebv || !d_reward)
-    return fail(BH_ERR_BAD_ARG, "bh_step_bind: need n_envs, n_out > 0, 2 <= depth <= 64, reward_pitch >= 1 and the slot tables");
+  if (n_envs <= 0 || n_out <= 0 || depth < 2 || depth > 4096 || n_rewards < 0 || n_rewards > 4096 || reward_pitch < 1 ||
+      !d_state || !d_gebv || (n_rewards > 0 && !d_reward))
+    return fail(BH_ERR_BAD_ARG, "bh_step_bind: need n_envs, n_out > 0, 2 <= depth <= 4096, reward_pitch >= 1 and the block tables");
   for (int64_t s = 0; s < depth; ++s)
-    if (!d_state[s] || !d_gebv[s] || !d_reward[s] || (d_obs && !d_obs[s]))
-      return fail(BH_ERR_BAD_ARG, "bh_step_bind: slot %lld has a null buffer", (long long)s);
+    if (!d_state[s] || !d_gebv[s] || (d_obs && !d_obs[s]))
+      return fail(BH_ERR_BAD_ARG, "bh_step_bind: slot %lld has a null block", (long long)s);
+  for (int64_t s = 0; s < n_rewards; ++s)
+    if (!d_reward[s]) return fail(BH_ERR_BAD_ARG, "bh_step_bind: reward block %lld is null", (long long)s);
   c->ring.n_envs = n_envs;
   c->ring.n_out = n_out;
   c->ring.depth = depth;
+  c->ring.n_rewards = n_rewards;
   c->ring.reward_pitch = reward_pitch;
   c->ring.state.assign(d_state, d_state + depth);
   c->ring.gebv.assign(d_gebv, d_gebv + depth);
-  c->ring.reward.assign(d_reward, d_reward + depth);
+  c->ring.reward.assign(d_reward, d_reward + n_rewards);
   if (d_obs)
     c->ring.obs.assign(d_obs, d_obs + depth);
   else
@@ -723,20 +727,21 @@ int bh_step_bind(bh_ctx *c, int64_t n_envs, int64_t n_out, int64_t depth, void *
   return BH_OK;
 }
 
-int bh_step(bh_ctx *c, int64_t slot, int64_t prime_slot, const uint16_t *d_pool, int64_t pool_rows,
+int bh_step(bh_ctx *c, int64_t slot, int64_t reward_slot, int64_t prime_slot, const uint16_t *d_pool, int64_t pool_rows,
             const int32_t *d_actions, uint32_t sim_key[2], int flags) {
   if (!c) return fail(BH_ERR_BAD_ARG, "null context");
   const auto &r = c->ring;
-  if (r.depth == 0) return fail(BH_ERR_BAD_ARG, "bh_step: no ring bound (bh_step_bind)");
-  if (slot < 0 || slot >= r.depth || prime_slot >= r.depth || prime_slot == slot)
-    return fail(BH_ERR_BAD_ARG, "bh_step: slot %lld / prime_slot %lld outside the ring of %lld", (long long)slot,
-                (long long)prime_slot, (long long)r.depth);
+  if (r.depth == 0) return fail(BH_ERR_BAD_ARG, "bh_step: no blocks bound (bh_step_bind)");
+  if (slot < 0 || slot >= r.depth || reward_slot >= r.n_rewards || prime_slot >= r.n_rewards ||
+      (prime_slot >= 0 && prime_slot == reward_slot))
+    return fail(BH_ERR_BAD_ARG, "bh_step: slot %lld / reward %lld / prime %lld outside the bound tables (%lld, %lld)",
+                (long long)slot, (long long)reward_slot, (long long)prime_slot, (long long)r.depth, (long long)r.n_rewards);
   if ((flags & BH_STEP_OBSERVATION) && !r.obs[(size_t)slot])
-    return fail(BH_ERR_BAD_ARG, "bh_step: the ring was bound without observation blocks");
+    return fail(BH_ERR_BAD_ARG, "bh_step: the blocks were bound without observations");
   return cross_impl(c, "bh_step", true, d_pool, r.n_envs, pool_rows, d_actions, r.n_out, sim_key, flags & 3,
                     (flags & BH_STEP_OBSERVATION) ? static_cast<uint8_t *>(r.obs[(size_t)slot]) : nullptr,
                     static_cast<uint16_t *>(r.state[(size_t)slot]), static_cast<float *>(r.gebv[(size_t)slot]),
-                    (flags & BH_STEP_REWARD) ? static_cast<float *>(r.reward[(size_t)slot]) : nullptr,
+                    reward_slot >= 0 ? static_cast<float *>(r.reward[(size_t)reward_slot]) : nullptr,
                     prime_slot >= 0 ? static_cast<float *>(r.reward[(size_t)prime_slot]) : nullptr, r.reward_pitch);
 }
 

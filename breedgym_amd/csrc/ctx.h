@@ -105,7 +105,7 @@ struct bh_ctx {
   int64_t primed_envs = 0, primed_pitch = 0;
   // bh_step_bind: the caller's ring of output blocks for bh_step
   struct {
-    int64_t n_envs = 0, n_out = 0, depth = 0, reward_pitch = 1;
+    int64_t n_envs = 0, n_out = 0, depth = 0, n_rewards = 0, reward_pitch = 1;
     std::vector<void *> state, obs, gebv, reward;
   } ring;
   bool big_lds_set = false;

@@ -11,6 +11,7 @@ bytes; bytes ``[2m, 2m+1]`` of a row are the two alleles of marker ``m`` (the re
 """
 import ctypes
 import math
+import sys
 from typing import Optional
 
 import numpy as np
@@ -91,65 +92,135 @@ class PackedPopulation:
         return self.unpack()[item]
 
 
+class _Blocks:
+    """A set of device blocks with the views handed out of them, and a cheap test for "nobody outside still holds
+    any of it": the Python reference counts of the handed-out objects and the use counts of their storages (a slice
+    or a ``view`` a caller made shares the storage) are what they were when only the pool held them."""
+
+    def __init__(self, tensors, handed_out):
+        self.storages = tuple(t.untyped_storage() for t in tensors)  # kept: their use counts include these wrappers
+        self.cdata = tuple(st._cdata for st in self.storages)
+        self.handed_out = tuple(handed_out)
+        self.base = self._counts()
+
+    def _counts(self, use_count=torch._C._storage_Use_Count, refcount=sys.getrefcount):
+        return [use_count(c) for c in self.cdata] + [refcount(o) for o in self.handed_out]
+
+    def free(self) -> bool:
+        return self._counts() == self.base
+
+
 class StepRing:
-    """The output blocks of ``VecBreedGym.step``, allocated once and reused in turn (include/breedhip.h, bh_step_bind).
+    """The output blocks of ``VecBreedGym.step``, kept and reused instead of allocated per step (include/breedhip.h,
+    bh_step_bind): a generation slot holds the bit-plane state, the byte-layout observation (unless the env hands out
+    lazy ones) and the GEBV, each with the Python views the env returns already made; rewards have small blocks of
+    their own (a launch primes the block of the NEXT step's reward).  ``step`` is the whole host side of a
+    generation: find a free slot, one ``bh_step`` call.
 
-    Slot s holds a generation: bit-plane state, byte-layout observation (unless the env hands out lazy ones), GEBV
-    and reward, each with the Python views the env returns already made.  ``step`` is the whole host side of a
-    generation: pick the next slot, one ``bh_step`` call.  What a slot held ``depth`` steps ago is overwritten --
-    an observation stays valid for ``depth - 1`` further steps / resets."""
+    A slot is reused only when nothing handed out of it is referenced any more (``_Blocks.free``), so what a caller
+    keeps stays valid for as long as it is kept -- the reference's arrays behave that way -- and a loop that drops
+    what it got alternates between two slots: the 164 MB of two observation blocks of 16 x 256 x 10k stay in the
+    256 MB Infinity Cache, which a fixed ring of three or more does not (24.5 against 26.3-29.3 us per step,
+    profiles/r03_ring_depth.txt).  When every slot is held the pool grows, up to ``max_slots``."""
 
-    OBS, REWARD = 4, 8  # bh_step flags
+    OBS = 4  # bh_step flag
 
-    def __init__(self, eng, n_envs, n_out, depth, with_observations):
-        if depth < 2:
-            raise ValueError("a step ring needs at least two slots")
-        self.eng, self.n_envs, self.n_out, self.depth = eng, int(n_envs), int(n_out), int(depth)
-        rows, dev = self.n_envs * self.n_out, eng.device
-        self.state = [torch.empty((rows, eng.packed_pitch), dtype=torch.uint8, device=dev) for _ in range(depth)]
-        self.obs_rows = [torch.empty((rows, eng.pitch), dtype=torch.uint8, device=dev) if with_observations else None
-                         for _ in range(depth)]
-        self.gebv = [torch.empty((n_envs, n_out, eng.n_traits), dtype=torch.float32, device=dev).as_subclass(DeviceArray)
-                     for _ in range(depth)]
-        self.reward = [torch.empty_strided((n_envs,), (64,), dtype=torch.float32, device=dev).as_subclass(DeviceArray)
-                       for _ in range(depth)]
-        # what the env hands out, made once
-        self.populations = [None if r is None else eng.as_genotypes(r, n_envs, n_out) for r in self.obs_rows]
-        self.lazy = [PackedPopulation(eng, st, (n_envs, n_out)) for st in self.state]
-        self.state_ptr = [t.data_ptr() for t in self.state]
-        self.cursor = depth - 1  # the slot written last
-
-        def table(ts):
-            return (ctypes.c_void_p * depth)(*[t.data_ptr() for t in ts])
-
-        _lib.check(eng._L.bh_step_bind(
-            eng._h, self.n_envs, self.n_out, depth, table(self.state), table(self.obs_rows) if with_observations else None,
-            table(self.gebv), table(self.reward), 64))
+    def __init__(self, eng, n_envs, n_out, with_observations, max_slots=16):
+        self.eng, self.n_envs, self.n_out = eng, int(n_envs), int(n_out)
+        self.with_observations, self.max_slots = bool(with_observations), int(max_slots)
+        self.slots, self.state, self.obs_rows, self.populations, self.gebv, self.lazy = [], [], [], [], [], []
+        self.rewards, self.reward = [], []
+        self.reserved = None  # the reward block the last launch primed for the next step
         self._bh_step, self._h = eng._L.bh_step, eng._h
         self._key_obj = self._key_ptr = None
+        for _ in range(2):
+            self._add_slot()
+        for _ in range(4):
+            self._add_reward()
+        self._bind()
 
-    def take(self) -> int:
-        """Claim the next slot (a reset gathers its founders into it)."""
-        self.cursor = s = (self.cursor + 1) % self.depth
-        self.lazy[s]._bytes = None
-        return s
+    def _add_slot(self):
+        eng, rows, dev = self.eng, self.n_envs * self.n_out, self.eng.device
+        state = torch.empty((rows, eng.packed_pitch), dtype=torch.uint8, device=dev)
+        obs = torch.empty((rows, eng.pitch), dtype=torch.uint8, device=dev) if self.with_observations else None
+        gebv = torch.empty((self.n_envs, self.n_out, eng.n_traits), dtype=torch.float32, device=dev).as_subclass(DeviceArray)
+        pops = None if obs is None else eng.as_genotypes(obs, self.n_envs, self.n_out)
+        lazy = PackedPopulation(eng, state, (self.n_envs, self.n_out))
+        self.state.append(state)
+        self.obs_rows.append(obs)
+        self.populations.append(pops)
+        self.gebv.append(gebv)
+        self.lazy.append(lazy)
+        self.slots.append(_Blocks([t for t in (state, obs, gebv) if t is not None],
+                                  [o for o in (state, obs, pops, gebv, lazy) if o is not None]))
 
-    def step(self, pool_ptr: int, pool_rows: int, idx: torch.Tensor, key: np.ndarray, flags: int, prime_ahead: int) -> int:
-        """One generation into the next slot; ``prime_ahead`` (0: none) = how many slots ahead the next step that
-        has a reward will write.  Returns the slot."""
+    def _add_reward(self):
+        r = torch.empty_strided((self.n_envs,), (64,), dtype=torch.float32, device=self.eng.device).as_subclass(DeviceArray)
+        self.reward.append(r)
+        self.rewards.append(_Blocks([r], [r]))
+
+    def _bind(self):
+        def table(ts):
+            return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+        _lib.check(self.eng._L.bh_step_bind(
+            self._h, self.n_envs, self.n_out, len(self.state), table(self.state),
+            table(self.obs_rows) if self.with_observations else None, table(self.gebv), len(self.reward),
+            table(self.reward), 64))
+
+    def take(self):
+        """A generation slot nobody holds any more (the pool grows when there is none; None when it may not)."""
+        for s, blocks in enumerate(self.slots):
+            if blocks.free():
+                self.lazy[s]._bytes = None
+                return s
+        if len(self.slots) >= self.max_slots:
+            return None
+        self._add_slot()
+        self._bind()
+        return len(self.slots) - 1
+
+    def take_reward(self, but=None):
+        for r, blocks in enumerate(self.rewards):
+            if r != but and r != self.reserved and blocks.free():
+                return r
+        if len(self.rewards) >= 4 * self.max_slots:
+            return None
+        self._add_reward()
+        self._bind()
+        return len(self.rewards) - 1
+
+    def step(self, pool_ptr: int, pool_rows: int, idx: torch.Tensor, key: np.ndarray, flags: int, want_reward: bool,
+             want_next: bool):
+        """One generation into a free slot -> (slot, reward block or None); None when no slot may be taken.
+        ``want_next``: prime a reward block for the next step that has a reward."""
         s = self.take()
+        if s is None:
+            return None
+        r = -1
+        if want_reward:
+            r, self.reserved = self.reserved, None
+            if r is None:
+                r = self.take_reward()  # not primed: the library fills it first
+                if r is None:
+                    return None
+        nxt = -1
+        if want_next:
+            nxt = self.take_reward(but=r)
+            self.reserved = nxt
+            if nxt is None:
+                nxt = -1
         if key is not self._key_obj:
             assert key.dtype == np.uint32 and key.shape == (2,) and key.flags.c_contiguous
             self._key_obj, self._key_ptr = key, key.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
-        rc = self._bh_step(self._h, s, (s + prime_ahead) % self.depth if prime_ahead else -1, pool_ptr, pool_rows,
-                           idx.data_ptr(), self._key_ptr, flags)
+        rc = self._bh_step(self._h, s, r, nxt, pool_ptr, pool_rows, idx.data_ptr(), self._key_ptr, flags)
         if rc:
             _lib.check(rc)
-        return s
+        return s, (r if r >= 0 else None)
 
     def close(self):
         if self.eng._h:
-            self.eng._L.bh_step_bind(self.eng._h, 0, 0, 0, None, None, None, None, 1)
+            self.eng._L.bh_step_bind(self.eng._h, 0, 0, 0, None, None, None, 0, None, 1)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -376,10 +447,10 @@ class HipEngine(EngineBase):
             _lib.check(rc)
         return outp, out, gebv, nxt
 
-    def step_ring(self, n_envs: int, n_out: int, depth: int, with_observations: bool) -> "StepRing":
-        """``depth`` slots of output blocks for ``VecBreedGym.step``, bound to the context (bh_step_bind): a step
-        then is one C call with no allocation (``StepRing.step``)."""
-        return StepRing(self, n_envs, n_out, depth, with_observations)
+    def step_ring(self, n_envs: int, n_out: int, with_observations: bool, max_slots: int = 16) -> "StepRing":
+        """Reusable output blocks for ``VecBreedGym.step``, bound to the context (bh_step_bind): a step then is one
+        C call with no allocation (``StepRing.step``)."""
+        return StepRing(self, n_envs, n_out, with_observations, max_slots)
 
     def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None) -> None:
         """Rows ``idx`` (or 0..n_rows-1) of packed ``src`` -> packed and/or byte-layout rows and/or GEBV."""

@@ -22,12 +22,12 @@ Differences a caller can see, all opt-in or benign:
     (``env.populations``, ``np.asarray(obs)``), for policies that only look at ``infos["GEBV"]``.
     ``storage="bytes"`` keeps the byte layout as the state (the step then reads 4M bytes of parents per
     cross instead of M/2; same results, bit for bit);
-  * ``ring_depth=4`` (default, with ``storage="bits"``): what ``step`` / ``reset`` hand out -- observation,
-    ``infos["GEBV"]``, a device-side reward -- lives in a ring of blocks allocated once, and is overwritten
-    ``ring_depth`` steps / resets later (a step is then one C call with nothing to allocate: 8 us of host time
-    less on the 23 us step of 16 x 256 x 10k).  Keep it longer by copying it (``np.asarray`` does), or ask for a
-    fresh block per step with ``ring_depth=0`` -- the reference's semantics, arrays that live as long as
-    somebody refers to them.
+  * ``block_pool=16`` (default, with ``storage="bits"``): what ``step`` / ``reset`` hand out -- observation,
+    ``infos["GEBV"]``, a device-side reward -- lives in blocks the env keeps and reuses once nothing handed out
+    of them is referenced any more (Python reference counts and storage use counts), so a step is one C call with
+    nothing to allocate (7 us of host time instead of 19 on the 23 us step of 16 x 256 x 10k) and whatever a caller
+    keeps stays valid for as long as it is kept, like the reference's arrays.  At most ``block_pool`` generations
+    are kept alive that way; beyond, and with ``block_pool=0``, every step allocates fresh blocks.
 """
 from pathlib import Path
 from typing import Optional, Tuple, Union
@@ -64,7 +64,7 @@ class VecBreedGym(_VectorEnvBase):
         sync_rewards: bool = True,
         storage: str = "bits",
         observations: str = "eager",
-        ring_depth: int = 4,
+        block_pool: int = 16,
         **kwargs,
     ):
         if env_rng not in ("shared", "independent"):
@@ -75,11 +75,11 @@ class VecBreedGym(_VectorEnvBase):
             raise ValueError("observations must be 'eager' or 'lazy'")
         if observations == "lazy" and storage != "bits":
             raise ValueError("observations='lazy' needs storage='bits'")
-        if ring_depth in (1, 2) or ring_depth < 0:
-            raise ValueError("ring_depth must be 0 (a fresh block per step) or at least 3")
+        if block_pool == 1 or block_pool < 0:
+            raise ValueError("block_pool must be 0 (a fresh block per step) or at least 2")
         self.storage = storage
         self.observations = observations
-        self.ring_depth = ring_depth
+        self.block_pool = block_pool
         self.num_envs = num_envs
         self.num_generations = num_generations
         self.autoreset = autoreset
@@ -120,7 +120,8 @@ class VecBreedGym(_VectorEnvBase):
         self._germ_prows = None
         self._n = None
         self._fast_step = hasattr(self.simulator.engine, "cross_step")  # the thin call of the HIP engine
-        self._ring = None  # StepRing: the output blocks of step(), reused in turn (storage="bits" on the HIP engine)
+        self._stage, self._stage_turn = {}, 0  # pinned staging blocks for host actions, two per shape, used in turn
+        self._ring = None  # StepRing: the output blocks of step(), kept and reused (storage="bits" on the HIP engine)
         self._all_false, self._all_true = np.full(self.num_envs, False), np.full(self.num_envs, True)
         self._founders_ahead = None  # (indices, key after the draw) made by the horizon step's launch for its reset
         self._rew_primed = None  # (E,) f32 the last cross launch left holding -inf: the next step's reward buffer
@@ -170,9 +171,27 @@ class VecBreedGym(_VectorEnvBase):
                 a = a.to(device=eng.device, dtype=torch.int32).contiguous()
         else:
             a = np.asarray(actions)
-            if a.dtype != np.int32:
-                a = a.astype(np.int32)
-            a = torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+            if a.ndim != 3 or a.shape[0] != self.num_envs or a.shape[2] != 2:
+                raise ValueError(f"actions must have shape ({self.num_envs}, n, 2), got {a.shape}")
+            # host actions (the reference's jax.device_put, vec_env.py:88): converted to int32 straight into a pinned
+            # staging block and copied from there without blocking -- a pageable upload costs ~15 us of host time
+            stage = self._stage.get(a.shape)
+            if stage is None:
+                blocks = [torch.empty(a.shape, dtype=torch.int32) for _ in range(2)]
+                if eng.device.type == "cuda":
+                    blocks = [b.pin_memory() for b in blocks]
+                stage = self._stage[a.shape] = [(b, b.numpy(), None) for b in blocks]
+            k = self._stage_turn = 1 - self._stage_turn
+            pinned, view, ev = stage[k]
+            if ev is not None:
+                ev.synchronize()  # the copy that last read this block (two steps ago) is long done
+            np.copyto(view, a, casting="unsafe")
+            a = pinned.to(eng.device, non_blocking=True)
+            if eng.device.type == "cuda":
+                ev = ev or torch.cuda.Event()
+                ev.record()
+                stage[k] = (pinned, view, ev)
+            return a
         if a.dim() != 3 or a.shape[0] != self.num_envs or a.shape[2] != 2:
             raise ValueError(f"actions must have shape ({self.num_envs}, n, 2), got {tuple(a.shape)}")
         return a
@@ -214,7 +233,7 @@ class VecBreedGym(_VectorEnvBase):
         want_next = self.reward_shaping or next_idx + 1 == self.num_generations
         ring = self._ring
         if ring is not None and n_out == ring.n_out and self._prows is not None:
-            # ---- the usual step: one C call into the next slot of the ring, nothing allocated (engine.StepRing)
+            # ---- the usual step: one C call into a block nobody holds any more, nothing allocated (engine.StepRing)
             if done and self.autoreset:
                 # the reset that follows needs its founders: their draw depends on the env key only and rides on
                 # this step's launch instead of being a launch of its own (bh_founders_deferred)
@@ -226,28 +245,31 @@ class VecBreedGym(_VectorEnvBase):
             key = sim.random_key
             if key.dtype != np.uint32 or not key.flags.c_contiguous:
                 key = sim.random_key = np.ascontiguousarray(key, np.uint32)
-            flags = self._rng_mode | (ring.OBS if want_obs else 0) | (ring.REWARD if want_rew else 0)
-            # the slot the next step writes: the one after this, or two on when a reset takes a slot in between
-            slot = ring.step(self._prows.data_ptr(), n_pool, idx, key, flags,
-                             (2 if done and self.autoreset else 1) if want_next else 0)
-            self._prows, self._n = ring.state[slot], n_out
-            self._brows = ring.obs_rows[slot] if want_obs else None
-            self._populations = ring.populations[slot] if want_obs else None
-            self.step_idx += 1
-            infos = {"GEBV": ring.gebv[slot]}
-            if not want_rew:
-                rews = np.zeros(E)
-            elif self.sync_rewards:
-                rews = ring.reward[slot].cpu().numpy()  # the reference's np.max(...) also syncs here (vec_env.py:97-98)
-            else:
-                rews = ring.reward[slot]
-            if done and self.autoreset:
-                self.reset()  # like the reference: obs is post-reset, infos pre-reset (vec_env.py:102-107)
-            obs = self._populations if self.observations == "eager" else ring.lazy[ring.cursor]
-            return obs, rews, self._all_false.copy(), (self._all_true if done else self._all_false).copy(), infos
+            got = ring.step(self._prows.data_ptr(), n_pool, idx, key, self._rng_mode | (ring.OBS if want_obs else 0),
+                            want_rew, want_next)
+            if got is not None:
+                slot, rslot = got
+                self._prows, self._n = ring.state[slot], n_out
+                self._brows = ring.obs_rows[slot] if want_obs else None
+                self._populations = ring.populations[slot] if want_obs else None
+                self.step_idx += 1
+                infos = {"GEBV": ring.gebv[slot]}
+                if rslot is None:
+                    rews = np.zeros(E)
+                elif self.sync_rewards:
+                    rews = ring.reward[rslot].cpu().numpy()  # the reference's np.max(...) also syncs here (vec_env.py:97-98)
+                else:
+                    rews = ring.reward[rslot]
+                if done and self.autoreset:
+                    obs, _ = self.reset()  # like the reference: obs is post-reset, infos pre-reset (vec_env.py:102-107)
+                else:
+                    obs = self._populations if self.observations == "eager" else ring.lazy[slot]
+                return obs, rews, self._all_false.copy(), (self._all_true if done else self._all_false).copy(), infos
+            # every block is held by somebody and the pool may not grow: fresh blocks for this step
+            return self._step_allocating(idx, n_pool, n_out, done, want_rew, want_next, founders_drawn=True)
         return self._step_allocating(idx, n_pool, n_out, done, want_rew, want_next)
 
-    def _step_allocating(self, idx, n_pool, n_out, done, want_rew, want_next):
+    def _step_allocating(self, idx, n_pool, n_out, done, want_rew, want_next, founders_drawn=False):
         """``step`` with a fresh block per output (``ring_depth=0``, ``storage="bytes"``, a generation whose size
         differs from the ring's, an engine without the ring)."""
         sim, E = self.simulator, self.num_envs
@@ -260,7 +282,7 @@ class VecBreedGym(_VectorEnvBase):
             if rew_dev is None or rew_dev.shape[0] != E:
                 rew_dev = eng.empty_reward(E)  # not primed: the library fills it first
         if self.storage == "bits":
-            if done and self.autoreset:
+            if done and self.autoreset and not founders_drawn:
                 self._founders_ahead = eng.founders(self.random_key, E, len(self.germplasm), self.individual_per_gen,
                                                     deferred=True)
             want_obs = self.observations == "eager" and not (done and self.autoreset)
@@ -324,21 +346,22 @@ class VecBreedGym(_VectorEnvBase):
         if self.storage == "bits":
             if self._germ_prows is None:
                 self._germ_prows = eng.pack(self._germ_rows)
-            if self.ring_depth and hasattr(eng, "step_ring") and (
+            if self.block_pool and hasattr(eng, "step_ring") and (
                     self._ring is None or (self._ring.n_envs, self._ring.n_out) != (E, n)):
                 if self._ring is not None:
                     self._ring.close()
-                self._ring = eng.step_ring(E, n, self.ring_depth, self.observations == "eager")
-            if self._ring is not None:
+                self._ring = eng.step_ring(E, n, self.observations == "eager", self.block_pool)
+            slot = self._ring.take() if self._ring is not None else None
+            if slot is not None:
                 ring = self._ring
-                slot = ring.take()
                 gebv = ring.gebv[slot]
                 eng.gather_packed(self._germ_prows, idx, E * n, ring.state[slot], ring.obs_rows[slot], gebv)
                 self._prows, self._brows, self._populations, self._n = (ring.state[slot], ring.obs_rows[slot],
                                                                         ring.populations[slot], n)
                 self._rew_primed = None
-                self.reset_infos = {"GEBV": gebv}
-                return (self._populations if self.observations == "eager" else ring.lazy[slot]), self.reset_infos
+                # (a copy: holding the slot's own GEBV view until the next reset would keep the slot out of use)
+                self.reset_infos = {"GEBV": DeviceArray.wrap(gebv.as_subclass(torch.Tensor).clone())}
+                return (self._populations if self.observations == "eager" else ring.lazy[slot]), {"GEBV": gebv}
             gebv = eng.empty((E, n, eng.n_traits), torch.float32)
             prows = eng.empty_packed(E * n)
             rows = eng.empty_population(E * n) if self.observations == "eager" else None

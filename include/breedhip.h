@@ -193,24 +193,25 @@ int bh_cross_packed(bh_ctx *ctx, const uint16_t *d_pool, int64_t n_envs, int64_t
                     uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv, float *d_reward,
                     float *d_reward_next, int64_t reward_pitch);
 /* `VecBreedGym.step` (vec_env.py:79-107) on output blocks bound once: what a step loop repeats -- four output
- * pointers, sizes, pitches -- is handed over once, and a step is bh_cross_packed with five arguments that change.
- * The ring is `depth` slots of caller-owned device buffers (the caller decides how long a handed-out observation
- * stays valid: depth - 1 further steps), each
+ * pointers, sizes, pitches -- is handed over once, and a step is bh_cross_packed with the few arguments that change.
+ * The caller owns the blocks and decides which one a step writes (it alone knows which of them somebody still
+ * looks at): `depth` generation slots, each
  *   d_state[s]   (n_envs * n_out, packed_pitch)  the generation's bit planes
  *   d_obs[s]     (n_envs * n_out, pitch)         its byte-layout observation  (d_obs may be NULL: never wanted)
  *   d_gebv[s]    (n_envs, n_out, T) f32
- *   d_reward[s]  (n_envs) f32 at reward_pitch
- * depth 0 unbinds.  The tables are copied; the buffers must outlive the binding. */
+ * and, apart from them (a step primes the block of the NEXT step's reward, whose slot is not known yet),
+ *   d_reward[r]  (n_envs) f32 at reward_pitch, r < n_rewards.
+ * depth 0 unbinds.  The tables are copied; the blocks must outlive the binding. */
 int bh_step_bind(bh_ctx *ctx, int64_t n_envs, int64_t n_out, int64_t depth, void *const *d_state, void *const *d_obs,
-                 void *const *d_gebv, void *const *d_reward, int64_t reward_pitch);
-/* One step into slot `slot`: parents d_pool (n_envs, pool_rows, packed_pitch) -- normally the state of the slot
- * written last --, d_actions (n_envs, n_out, 2).  flags: bh_rng_mode in the low two bits, BH_STEP_OBSERVATION (write
- * the slot's byte-layout observation), BH_STEP_REWARD (max GEBV per env into the slot's reward block, vec_env.py:97).
- * prime_slot >= 0: that slot's reward block is left holding -inf for the step that will use it (bh_cross_packed's
- * d_reward_next); -1: none.  Everything else as bh_cross_packed. */
-enum { BH_STEP_OBSERVATION = 4, BH_STEP_REWARD = 8 };
-int bh_step(bh_ctx *ctx, int64_t slot, int64_t prime_slot, const uint16_t *d_pool, int64_t pool_rows,
-            const int32_t *d_actions, uint32_t sim_key[2], int flags);
+                 void *const *d_gebv, int64_t n_rewards, void *const *d_reward, int64_t reward_pitch);
+/* One step into generation slot `slot`: parents d_pool (n_envs, pool_rows, packed_pitch) -- normally the state of the
+ * slot written last --, d_actions (n_envs, n_out, 2).  flags: bh_rng_mode in the low two bits, BH_STEP_OBSERVATION
+ * (write the slot's byte-layout observation).  reward_slot >= 0: max GEBV per env into that reward block
+ * (vec_env.py:97); prime_slot >= 0: that reward block is left holding -inf for the step that will use it
+ * (bh_cross_packed's d_reward_next); -1: none.  Everything else as bh_cross_packed. */
+enum { BH_STEP_OBSERVATION = 4 };
+int bh_step(bh_ctx *ctx, int64_t slot, int64_t reward_slot, int64_t prime_slot, const uint16_t *d_pool,
+            int64_t pool_rows, const int32_t *d_actions, uint32_t sim_key[2], int flags);
 /* bh_gather on packed rows (vec_env.py:126-129).  d_idx NULL = rows 0..n_rows-1 in order, which
  * makes this the unpack (d_out_bytes only) and the GEBV of packed rows (d_gebv only).  Any of
  * d_out_packed, d_out_bytes, d_gebv may be NULL. */

@@ -275,10 +275,11 @@ def test_vec_env_bit_plane_storage(observations, env_rng):
 
 
 @pytest.mark.parametrize("observations", ["eager", "lazy"])
-def test_step_ring_equals_fresh_blocks(observations, rng):
-    """The default ring of output blocks (ring_depth=4, bh_step) against a fresh block per step (ring_depth=0,
-    bh_cross_packed): same observations, GEBV, rewards and key chains over two episodes incl. the autoreset; and
-    what a step hands out stays intact for ring_depth - 1 further steps."""
+def test_block_pool_equals_fresh_blocks(observations, rng):
+    """The default pool of reusable output blocks (bh_step) against a fresh block per step (block_pool=0,
+    bh_cross_packed): same observations, GEBV, rewards and key chains over two episodes incl. the autoreset; whatever
+    the caller keeps -- every observation, GEBV and device-side reward of the run here -- stays what it was (a block
+    is reused only when nothing handed out of it is referenced); a loop that keeps nothing alternates two blocks."""
     from breedgym_amd import VecBreedGym
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
 
@@ -287,27 +288,46 @@ def test_step_ring_equals_fresh_blocks(observations, rng):
     geno = synthetic_genotypes(N, M, seed=3)
     kw = dict(num_envs=E, initial_population=geno, individual_per_gen=n, genetic_map=gm, num_generations=G,
               reward_shaping=True, sync_rewards=False, observations=observations)
-    ring, fresh = VecBreedGym(ring_depth=4, **kw), VecBreedGym(ring_depth=0, **kw)
-    assert ring.reset(seed=9)[0].shape == fresh.reset(seed=9)[0].shape
-    assert ring._ring is not None and fresh._ring is None
-    held = []  # (step it came from, the handed-out observation, a host copy made at once)
+    pool, fresh = VecBreedGym(**kw), VecBreedGym(block_pool=0, **kw)
+    assert pool.reset(seed=9)[0].shape == fresh.reset(seed=9)[0].shape
+    assert pool._ring is not None and fresh._ring is None
+    held = []  # everything handed out, with a host copy made at once
     for t in range(2 * G + 1):
         a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
-        o1, r1, _, tr1, i1 = ring.step(a)
+        o1, r1, _, tr1, i1 = pool.step(a)
         o2, r2, _, tr2, i2 = fresh.step(a)
         assert np.array_equal(np.asarray(o1), np.asarray(o2)), t
         assert np.array_equal(np.asarray(i1["GEBV"]), np.asarray(i2["GEBV"]))
         assert np.array_equal(np.asarray(r1), np.asarray(r2)) and np.array_equal(tr1, tr2)
-        assert np.array_equal(ring.simulator.random_key, fresh.simulator.random_key)
-        assert np.array_equal(ring.random_key, fresh.random_key)
-        assert np.array_equal(np.asarray(ring.populations), np.asarray(fresh.populations))
-        held.append((t, o1, np.asarray(o1).copy()))
-        for t0, obs, copy in held[-2:]:  # the last two observations are still what they were (a reset may sit between)
-            assert np.array_equal(np.asarray(obs), copy), (t, t0)
+        assert np.array_equal(pool.simulator.random_key, fresh.simulator.random_key)
+        assert np.array_equal(pool.random_key, fresh.random_key)
+        assert np.array_equal(np.asarray(pool.populations), np.asarray(fresh.populations))
+        # kept in different ways: the object itself, a view of it, only its GEBV
+        held.append((o1 if t % 3 == 0 else (o1[1] if t % 3 == 1 else None), i1["GEBV"][..., 0], r1,
+                     np.asarray(o1).copy(), np.asarray(i1["GEBV"]).copy(), np.asarray(r1).copy()))
+        for obs, g, r, obs0, g0, r0 in held:
+            if obs is not None:
+                assert np.array_equal(np.asarray(obs), obs0 if obs.shape == obs0.shape else obs0[1]), t
+            assert np.array_equal(np.asarray(g), g0[..., 0]) and np.array_equal(np.asarray(r), r0), t
+    assert len(pool._ring.slots) > 2  # the pool grew to keep what is held
+    del held, o1, i1, r1
+    before = len(pool._ring.slots)
+    used = set()
+    for t in range(12):  # nothing kept: two blocks in turn (the rest stay idle)
+        pool.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))
+        used.add(pool._prows.data_ptr())
+    assert len(pool._ring.slots) == before and len(used) <= 3, (before, len(used))
     # a wrapper may replace the populations (breeding_programs_env.py:56): the next step reads them
+    fresh.reset(seed=4)
+    pool.reset(seed=4)
     newpop = np.asarray(fresh.populations).copy()[:, ::-1]
-    ring.populations, fresh.populations = newpop, newpop
+    pool.populations, fresh.populations = newpop, newpop
     a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
-    assert np.array_equal(np.asarray(ring.step(a)[0]), np.asarray(fresh.step(a)[0]))
+    assert np.array_equal(np.asarray(pool.step(a)[0]), np.asarray(fresh.step(a)[0]))
+    # a pool that may not grow falls back to fresh blocks when everything is held
+    tiny = VecBreedGym(block_pool=2, **kw)
+    tiny.reset(seed=9)
+    keep = [tiny.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))[0] for _ in range(5)]
+    assert len({k.data_ptr() if hasattr(k, "data_ptr") else id(k) for k in keep}) == 5 and len(tiny._ring.slots) == 2
     with pytest.raises(ValueError):
-        VecBreedGym(ring_depth=2, **kw)
+        VecBreedGym(block_pool=1, **kw)
