@@ -101,6 +101,9 @@ class _Blocks:
         self.storages = tuple(t.untyped_storage() for t in tensors)  # kept: their use counts include these wrappers
         self.cdata = tuple(st._cdata for st in self.storages)
         self.handed_out = tuple(handed_out)
+        self.base = None  # rebase(): once the pool alone holds the objects
+
+    def rebase(self):
         self.base = self._counts()
 
     def _counts(self, use_count=torch._C._storage_Use_Count, refcount=sys.getrefcount):
@@ -153,11 +156,15 @@ class StepRing:
         self.lazy.append(lazy)
         self.slots.append(_Blocks([t for t in (state, obs, gebv) if t is not None],
                                   [o for o in (state, obs, pops, gebv, lazy) if o is not None]))
+        del state, obs, gebv, pops, lazy  # the counts of "nobody else holds it" are taken without these names
+        self.slots[-1].rebase()
 
     def _add_reward(self):
         r = torch.empty_strided((self.n_envs,), (64,), dtype=torch.float32, device=self.eng.device).as_subclass(DeviceArray)
         self.reward.append(r)
         self.rewards.append(_Blocks([r], [r]))
+        del r
+        self.rewards[-1].rebase()
 
     def _bind(self):
         def table(ts):
