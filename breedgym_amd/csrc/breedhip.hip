@@ -269,7 +269,6 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_spare) (void)hipFree(c->d_spare);
   if (c->d_sort) (void)hipFree(c->d_sort);
   if (c->d_best) (void)hipFree(c->d_best);
-  if (c->d_pk) (void)hipFree(c->d_pk);
   if (c->d_F) (void)hipFree(c->d_F);
   if (c->d_thrA) (void)hipFree(c->d_thrA);
   if (c->d_thrB) (void)hipFree(c->d_thrB);

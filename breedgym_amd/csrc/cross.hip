@@ -417,31 +417,12 @@ int launch_pack(bh_ctx *c, const bh::PackParams &p) {
   return BH_OK;
 }
 
-constexpr int64_t kGebvViaBitsMin = 1ll << 25;  // rows x markers from which byte-layout rows go through bit planes
+constexpr int64_t kGebvViaPlanesMin = 1ll << 25;  // rows x markers from which byte-layout rows take the one-pass plane route
 int gebv_chunks(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv, int t_begin) {
-  // large byte-layout populations: to bit planes first (the read of the byte rows at streaming rate, 1/8 of them
-  // written), then the matrix-core pass over those (gebv_bits.h) -- 2048 x 100k x 8: 158 -> 115 us; long rows of one
-  // or two traits: instead of the f64 stream
-  if (t_begin == 0 && use_bits_gebv(c, rows) && rows * c->M >= kGebvViaBitsMin) {
-    const int64_t bytes = rows * 16 * c->nw;
-    if (c->pk_cap < bytes) {
-      BH_HIP(hipStreamSynchronize(c->stream));
-      if (c->d_pk) BH_HIP(hipFree(c->d_pk));
-      c->d_pk = nullptr;
-      c->pk_cap = 0;
-      BH_HIP(hipMalloc(&c->d_pk, (size_t)bytes));
-      c->pk_cap = bytes;
-    }
-    bh::PackParams pp{};
-    pp.src = d_pop;
-    pp.dst = c->d_pk;
-    pp.pitch = c->pitch;
-    pp.nvec = c->nvec;
-    pp.nvp = 8 * c->nw;
-    pp.n_rows = (int32_t)rows;
-    if (int rc = launch_pack(c, pp)) return rc;
-    return gebv_bits(c, c->d_pk, rows, nullptr, rows, d_gebv);
-  }
+  // large byte-layout populations: one pass that turns the rows into bit planes inside LDS and runs the matrix-core
+  // digit GEMMs of gebv_bits.h on those (gebv_bytes.h) -- 2048 x 100k x 8: 158 us (gebv_mfma_kernel) -> 115 us (round 2:
+  // planes through HBM) -> this; long rows of one or two traits: instead of the f64 stream
+  if (t_begin == 0 && use_bits_gebv(c, rows) && rows * c->M >= kGebvViaPlanesMin) return gebv_bytes(c, d_pop, rows, d_gebv);
   if (t_begin == 0 && use_mfma_gebv(c, rows)) return gebv_mfma(c, d_pop, rows, d_gebv);
   for (int t0 = t_begin; t0 < c->T; t0 += kMaxFusedTraits) {
     bh::RowParams p = base_params(c);

@@ -60,8 +60,6 @@ struct bh_ctx {
   int64_t z_cap[2] = {0, 0};  // bytes
   char *d_spare = nullptr;    // 16 KB nobody reads (PackedParams::spare)
   uint64_t *d_S = nullptr;    // site words of the stream-per-lane mask role (mask_stream.h)
-  uint16_t *d_pk = nullptr;   // bit planes of byte-layout rows on their way to gebv_bits (gebv_chunks)
-  int64_t pk_cap = 0;         // bytes
   int64_t s_cap = 0;          // bytes
   float mutation = 0.0f;      // bh_set_mutation: chromax's mutation probability (0: off, the hot path)
   uint32_t mut_thr = 0;       // (bits >> 9) < mut_thr  <=>  uniform_f32(bits) < mutation
@@ -123,6 +121,7 @@ int ensure_scratch(bh_ctx *c, void **buf, int64_t *cap, int64_t bytes);
 // gebv.hip: GEBV passes on the matrix cores, all traits
 int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv);
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv);
+int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv);
 
 // select.hip: a deferred founder draw that found no launch to ride on is made now, in stream order
 int flush_founders(bh_ctx *c);

@@ -2,6 +2,7 @@
 // selection indices (bh_optimal_haploid).
 #include "ctx.h"
 #include "gebv_bits.h"
+#include "gebv_bytes.h"
 #include "gebv_mfma.h"
 #include "index_kernels.h"
 
@@ -58,7 +59,8 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
 
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
-constexpr int kGebvBitsWgs = 512;  // workgroups the K slicing aims at
+constexpr int kGebvBitsWgs = 512;
+constexpr int kGebvBytesWgs = 1024;  // ... and the byte-row pass (its workgroups hide HBM latency, not MFMA latency)  // workgroups the K slicing aims at
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
 constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
@@ -90,11 +92,66 @@ constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
     p.rows_pad = (int32_t)rows_pad;
     p.n_mc = c->n_mc;
     p.mc_per_slice = (int32_t)per_slice;
-    const dim3 grid((unsigned)row_groups, (unsigned)slices);
+    p.row_groups = (int32_t)row_groups;
+    p.slices = (int32_t)slices;
+    const dim3 grid((unsigned)(8 * row_groups * ((slices + 7) / 8)));
     if (nt == 1)
       hipLaunchKernelGGL((bh::gebv_bits_kernel<1, F>), grid, dim3(256), 0, c->stream, p);
     else
       hipLaunchKernelGGL((bh::gebv_bits_kernel<2, F>), grid, dim3(256), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+    bh::GebvFinishParams f{};
+    f.partial = c->d_partial;
+    f.scale = c->d_scale + t0;
+    f.gebv = d_gebv;
+    f.rows = (int32_t)rows;
+    f.rows_pad = (int32_t)rows_pad;
+    f.slices = (int32_t)slices;
+    f.T = (int32_t)tn;
+    f.Tstride = (int32_t)c->T;
+    f.t0 = (int32_t)t0;
+    f.cols = 32 * nt;
+    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
+    BH_HIP(hipGetLastError());
+  }
+  return BH_OK;
+}
+
+// GEBV of byte-layout rows in one pass: planes built in LDS, then gebv_bits' matrix-core pass (gebv_bytes.h)
+int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
+  constexpr int kTraitsPerPack = kGebvCols / kGebvDigits;
+  const int64_t row_groups = (rows + 127) / 128, rows_pad = row_groups * 128;
+  // enough workgroups to keep ~16 KB of row loads per wave in flight on every CU: HBM-bound
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((kGebvBytesWgs + row_groups - 1) / row_groups, c->n_mc));
+  const int64_t per_slice = (c->n_mc + slices - 1) / slices;
+  slices = (c->n_mc + per_slice - 1) / per_slice;
+  const int64_t need = slices * rows_pad * kGebvCols;
+  void *part = c->d_partial;
+  int64_t cap = c->partial_cap * (int64_t)sizeof(int32_t);
+  const int rc0 = ensure_scratch(c, &part, &cap, need * (int64_t)sizeof(int32_t));
+  c->d_partial = static_cast<int32_t *>(part);
+  c->partial_cap = cap / (int64_t)sizeof(int32_t);
+  if (rc0) return rc0;
+  for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
+    const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
+    const int nt = tn * kGebvDigits > 32 ? 2 : 1;
+    bh::GebvBytesParams p{};
+    p.rows = d_pop;
+    p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
+    p.partial = c->d_partial;
+    p.pitch = c->pitch;
+    p.n_rows = (int32_t)rows;
+    p.rows_pad = (int32_t)rows_pad;
+    p.nvec = c->nvec;
+    p.n_mc = c->n_mc;
+    p.mc_per_slice = (int32_t)per_slice;
+    p.row_groups = (int32_t)row_groups;
+    p.slices = (int32_t)slices;
+    const dim3 grid((unsigned)(8 * row_groups * ((slices + 7) / 8)));
+    if (nt == 1)
+      hipLaunchKernelGGL((bh::gebv_bytes_kernel<1>), grid, dim3(256), 0, c->stream, p);
+    else
+      hipLaunchKernelGGL((bh::gebv_bytes_kernel<2>), grid, dim3(256), 0, c->stream, p);
     BH_HIP(hipGetLastError());
     bh::GebvFinishParams f{};
     f.partial = c->d_partial;

@@ -42,7 +42,20 @@ struct GebvBitsParams {
   int32_t n_src, n_rows, rows_pad;
   int32_t n_mc;          // ceil(M / 512)
   int32_t mc_per_slice;
+  int32_t row_groups, slices;  // the grid: 8 * row_groups * ceil(slices / 8) workgroups (slice_of_block)
 };
+
+// Which (row group, K slice) a workgroup takes.  Workgroups b, b + 8, ... share an XCD and with it an L2
+// (MI355X_MICROARCH.md, workgroup dispatch): every XCD is handed whole K slices -- slice s goes to the blocks with
+// b % 8 == s % 8, row groups innermost -- so that a slice's digit operands (32 KB per 512 markers; 6.4 MB for 100k
+// markers, more than one L2 holds) come into that L2 once and are met there by every row group, instead of every
+// XCD pulling the whole pack through the fabric once per row group.  Placement only changes speed.
+__device__ __forceinline__ bool slice_of_block(int row_groups, int slices, int &rg, int &slice) {
+  const int b = (int)blockIdx.x, i = b >> 3;
+  rg = i % row_groups;
+  slice = (i / row_groups) * 8 + (b & 7);
+  return slice < slices;
+}
 
 // 16 markers (one dword of a bit-plane row: bits 2k, 2k+1 = the alleles of marker k) -> 16 dosage bytes.
 // The order of the bytes is free (the digit operand is packed to match), so no field is moved further than
@@ -65,14 +78,15 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
   __shared__ i32x4 ldsB[2][STAGE_V];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int slice = blockIdx.y;
+  int rg, slice;
+  if (!slice_of_block(p.row_groups, p.slices, rg, slice)) return;  // uniform per workgroup
   const int mc_begin = slice * p.mc_per_slice;
   const int mc_end = min(p.n_mc, mc_begin + p.mc_per_slice);
   const int n_stages = (mc_end - mc_begin) * (4 / QS);  // > 0 by construction of the grid
 
   // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row
   // (its lanes re-read the last row; nothing of it is used by gebv_finish_kernel)
-  const int tile0 = (blockIdx.x * 4 + wave) * F;
+  const int tile0 = (rg * 4 + wave) * F;
   const uint8_t *pa[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) {

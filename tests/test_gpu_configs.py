@@ -671,3 +671,22 @@ def test_rows_beyond_the_lds_mask_limit(layout, M, C, mode, rng):
         eng.sync()
     finally:
         co.set_threefry_layout("original")
+
+
+@pytest.mark.parametrize("rows,M,T", [(333, 100_003, 8), (4100, 8_200, 1), (129, 262_144 + 8, 10), (2048, 16_400, 17),
+                                        (5000, 7_001, 3), (32, 1_048_583, 2)])
+def test_byte_row_gebv_in_one_pass(rows, M, T, rng):
+    """bh_gebv on large byte-layout populations (csrc/gebv_bytes.h: bit planes built in LDS, digit GEMMs on the matrix
+    cores): ragged row counts (tiles and row groups that reach past the last row), marker counts that are no multiple
+    of 8 / 512 (a last vector with pad bytes, a last chunk with missing vectors), one and two column tiles, more than
+    one pack of traits; effects with large and tiny magnitudes side by side."""
+    from breedgym_amd import HipEngine
+
+    assert rows * M >= 1 << 25
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    eff = (rng.laplace(0, 6, (M, T)) * 10.0 ** rng.integers(-3, 3, (1, T))).astype(np.float32)
+    eng = HipEngine(np.full(M, 0.01, np.float32), eff)
+    geno = (rng.random((rows, M, 2)) < 0.3).astype(np.uint8)
+    geno[0], geno[-1] = 1, 0  # the largest and the smallest sums
+    got = eng.gebv(eng.upload_population(geno)).cpu().numpy()
+    assert gebv_close(got, co.gebv(geno, eff, want64=True)[1])
