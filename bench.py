@@ -361,7 +361,8 @@ def bench_c5(reps):
     return {
         "workload": "BASELINE configs[4]: GEBV of 2048 x 100k markers x 8 traits, exact int8-digit products on MFMA",
         "byte_rows": {"ms": ms_bytes, "individuals_per_s": N / (ms_bytes * 1e-3),
-                      "roofline": roofline_of("pack_kernel + gebv_bits_kernel<2,1> + gebv_finish_kernel (bh_gebv, byte-layout rows: to bit planes, then the matrix-core pass)", N * 2 * M + eff_bytes, ms_bytes)},
+                      "roofline": roofline_of("gebv_bytes_kernel<2> + gebv_finish_kernel (bh_gebv, byte-layout rows in one pass: bit planes built in LDS, digit GEMMs on the matrix cores)", N * 2 * M + eff_bytes, ms_bytes,
+                                              traffic=committed_traffic("gebv_bytes_kernel<2")[0], traffic_source=committed_traffic("gebv_bytes_kernel<2")[1])},
         "bit_planes": {"ms": ms_bits, "individuals_per_s": N / (ms_bits * 1e-3),
                        "roofline": roofline_of("gebv_bits_kernel<2,1> + gebv_finish_kernel (bh_gather_packed, bit-plane rows)",
                                                N * packed_pitch(M) + eff_bytes, ms_bits,

@@ -60,7 +60,10 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
 constexpr int kGebvBitsWgs = 512;
-constexpr int kGebvBytesWgs = 1024;  // ... and the byte-row pass (its workgroups hide HBM latency, not MFMA latency)  // workgroups the K slicing aims at
+// ... and the byte-row pass: as many workgroups as are resident at once (three per CU: 152 VGPRs, 53 KB of LDS), never
+// more -- a second round of a few workgroups costs a whole round's time (784 workgroups: 117 us, 640: 91 us at
+// 2048 x 100k x 8, profiles/r03_ab_gebv_bytes.txt)
+constexpr int kGebvBytesWgs = 768;  // workgroups the K slicing aims at
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
 constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
@@ -122,7 +125,7 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = kGebvCols / kGebvDigits;
   const int64_t row_groups = (rows + 127) / 128, rows_pad = row_groups * 128;
   // enough workgroups to keep ~16 KB of row loads per wave in flight on every CU: HBM-bound
-  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((kGebvBytesWgs + row_groups - 1) / row_groups, c->n_mc));
+  int64_t slices = std::max<int64_t>(1, std::min<int64_t>(kGebvBytesWgs / row_groups, c->n_mc));
   const int64_t per_slice = (c->n_mc + slices - 1) / slices;
   slices = (c->n_mc + per_slice - 1) / per_slice;
   const int64_t need = slices * rows_pad * kGebvCols;

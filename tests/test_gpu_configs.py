@@ -673,7 +673,7 @@ def test_rows_beyond_the_lds_mask_limit(layout, M, C, mode, rng):
         co.set_threefry_layout("original")
 
 
-@pytest.mark.parametrize("rows,M,T", [(333, 100_003, 8), (4100, 8_200, 1), (129, 262_144 + 8, 10), (2048, 16_400, 17),
+@pytest.mark.parametrize("rows,M,T", [(340, 100_003, 8), (4100, 8_200, 1), (129, 262_144 + 8, 10), (2048, 16_400, 17),
                                         (5000, 7_001, 3), (32, 1_048_583, 2)])
 def test_byte_row_gebv_in_one_pass(rows, M, T, rng):
     """bh_gebv on large byte-layout populations (csrc/gebv_bytes.h: bit planes built in LDS, digit GEMMs on the matrix

@@ -1,5 +1,6 @@
-// Timing driver for GEBV from bit-plane rows through the C ABI (bh_gather_packed with only the GEBV output).
-// usage: abg [rows] [M] [T]     (tools/ab_build.sh builds variants; pass -DAB_MAIN_GEBV)
+// Timing driver for the GEBV passes through the C ABI: from bit-plane rows (bh_gather_packed with only the GEBV
+// output) and from byte-layout rows (bh_gebv).
+// usage: driver [rows] [M] [T]     (tools/ab_build.sh --driver tools/ablate_gebv.cpp builds variants)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,18 @@ int main(int argc, char **argv) {
   for (int i = 0; i < reps; ++i) bh_gather_packed(ctx, pool, rows, nullptr, rows, nullptr, nullptr, gebv);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  printf("rows=%lld M=%lld T=%lld : %.1f us per call\n", (long long)rows, (long long)M, (long long)T, ms / reps * 1e3);
+  printf("rows=%lld M=%lld T=%lld : bit planes %.1f us per call", (long long)rows, (long long)M, (long long)T, ms / reps * 1e3);
+  uint8_t *bytes;
+  const int64_t pitch = bh_row_pitch(ctx);
+  bh_alloc(ctx, rows * pitch, (void **)&bytes);
+  { std::vector<uint64_t> hb(rows * pitch / 8); for (auto &w : hb) w = rnd() & 0x0101010101010101ull;
+    bh_memcpy_h2d(ctx, bytes, hb.data(), hb.size() * 8); bh_sync(ctx); }
+  for (int i = 0; i < 5; ++i) bh_gebv(ctx, bytes, rows, gebv);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) bh_gebv(ctx, bytes, rows, gebv);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  hipEventElapsedTime(&ms, e0, e1);
+  printf(", byte rows %.1f us per call (%.2f TB/s)\n", ms / reps * 1e3, rows * pitch / (ms / reps * 1e-3) / 1e12);
   return 0;
 }
