@@ -11,9 +11,10 @@ cross launch, its double-haploid key mode, batched top-k and row gathers.
 reference tree; the per-line selection follows the intent shown in ``scripts/time_wheat.py:20-24``
 (``vmap(simulator.select)`` over lines).
 """
-import numpy as np
+import torch
 
-from .. import spaces
+from .. import _lib, spaces
+from ..engine import DeviceArray
 from .vec_wrappers import PairScores, VectorWrapper
 
 
@@ -37,9 +38,18 @@ class WheatBreedGym(VectorWrapper):
 
     def step(self, actions):
         env, sim = self.env, self.simulator
-        eng = sim.engine
-        E = self.num_envs
         low = self._convert_actions(actions)  # (E, n_lines, 2) indices into the current population
+        if env.storage == "bits" and env._prows is not None:
+            infos = self._generation_on_bit_planes(low)
+        else:
+            infos = self._generation_on_byte_rows(low)
+        return env._close_step(infos)
+
+    def _generation_on_byte_rows(self, low):
+        """cross -> doubled haploids -> the best of every line -> the best of those, every stage materialised in the
+        byte layout through the simulator's public operators (``storage="bytes"``)."""
+        env, sim = self.env, self.simulator
+        eng, E = sim.engine, self.num_envs
         f1 = eng.empty_population(E * self.n_lines)
         sim.cross_indexed(env._rows, E, env._n, low, self.n_lines, f1, None, env._rng_mode)
         f1 = eng.as_genotypes(f1, E, self.n_lines)
@@ -47,22 +57,36 @@ class WheatBreedGym(VectorWrapper):
         kept, _ = sim.select(dh, k=self.k_per_line)  # (E, L, k_per_line, M, 2)
         kept = kept.reshape(E, self.n_lines * self.k_per_line, sim.n_markers, 2)
         env.populations, _ = sim.select(kept, k=self.individual_per_gen)
+        return env.get_info()
 
-        env.step_idx += 1
-        infos = env.get_info()
-        done = env.step_idx == self.num_generations
-        if self.reward_shaping or done:
-            rews = np.max(infos["GEBV"], axis=(1, 2))
-            rews = np.asarray(rews)
-        else:
-            rews = np.zeros(self.num_envs)
-
-        if done and self.autoreset:
-            self.reset()
-
-        terminated = np.full(self.num_envs, False)
-        truncated = np.full(self.num_envs, done)
-        return self.populations, rews, terminated, truncated, infos
+    def _generation_on_bit_planes(self, low):
+        """The same generation with every population as bit planes (``storage="bits"``, the default): the 80,000
+        doubled haploids of 4 envs x 200 lines x 100 plants are 0.2 GB instead of 1.6 GB, their GEBV comes out of the
+        launch that makes them (or a pass over the planes), the selections gather plane rows, and only the
+        ``individual_per_gen`` survivors are expanded to the byte layout the step returns.  Same keys, same plants."""
+        env, sim = self.env, self.simulator
+        eng, E, L, P, K, n = sim.engine, self.num_envs, self.n_lines, self.plant_per_line, self.k_per_line, self.individual_per_gen
+        dev, T = eng.device, eng.n_traits
+        f1 = eng.empty_packed(E * L)
+        sim.cross_indexed_packed(env._prows, E, env._n, low, L, f1, None, None, env._rng_mode)
+        # every F1 gives P doubled haploids (Simulator.double_haploid's key plumbing: one key per plant)
+        one = torch.arange(L, dtype=torch.int32, device=dev).repeat_interleave(P)
+        idx = one.repeat(E).reshape(E, L * P, 1).expand(-1, -1, 2).contiguous()
+        dh, g = eng.empty_packed(E * L * P), eng.empty((E * L, P, T), torch.float32)
+        sim.cross_indexed_packed(f1, E, L, idx, L * P, dh, None, g, env._rng_mode | _lib.RNG_DOUBLE_HAPLOID)
+        # the K best plants of every line by the conventional index (the sum of the GEBVs over traits), best first
+        best = eng.topk(g.sum(dim=-1), K).to(torch.int64)  # (E * L, K)
+        flat = (best + torch.arange(E * L, device=dev).unsqueeze(1) * P).to(torch.int32).reshape(-1).contiguous()
+        kept, gk = eng.empty_packed(E * L * K), eng.empty((E, L * K, T), torch.float32)
+        eng.gather_packed(dh, flat, E * L * K, kept, None, gk)
+        # ... and the n best of an env's kept plants are the next population
+        best = eng.topk(gk.sum(dim=-1), n).to(torch.int64)  # (E, n)
+        flat = (best + torch.arange(E, device=dev).unsqueeze(1) * (L * K)).to(torch.int32).reshape(-1).contiguous()
+        newp, gn = eng.empty_packed(E * n), eng.empty((E, n, T), torch.float32)
+        newb = eng.empty_population(E * n) if env.observations == "eager" else None
+        eng.gather_packed(kept, flat, E * n, newp, newb, gn)
+        env._adopt(newb, n, newp)
+        return {"GEBV": DeviceArray.wrap(gn)}
 
 
 class _LinesView:

@@ -307,22 +307,25 @@ class VecBreedGym(_VectorEnvBase):
             sim.cross_indexed(self._brows, E, n_pool, idx, n_out, out, gebv, self._rng_mode, rew_dev, rew_next)
             self._adopt(out, n_out)
         self._rew_primed = rew_next
-        self.step_idx += 1
+        return self._close_step({"GEBV": gebv.as_subclass(DeviceArray)}, rew_dev)
 
-        infos = {"GEBV": gebv.as_subclass(DeviceArray)}
-        if rew_dev is None:
+    def _close_step(self, infos, rew_dev=None):
+        """What follows the new generation in any kind of step (vec_env.py:92-107): the generation is counted, the
+        reward -- max GEBV per env -- is handed out when it is due (from the launch that noted it, ``rew_dev``, or from a
+        reduction over ``infos["GEBV"]``), the horizon resets the envs, and the step's five values go back: the
+        observation is the post-reset one at the horizon, the infos are the pre-reset ones."""
+        self.step_idx += 1
+        done = self.step_idx == self.num_generations
+        if not (self.reward_shaping or done):
             rews = np.zeros(self.num_envs)
+        elif rew_dev is None:
+            rews = self._rewards(infos["GEBV"].as_subclass(torch.Tensor))
         elif self.sync_rewards:
             rews = rew_dev.cpu().numpy()  # the reference's np.max(...) also syncs here (vec_env.py:97-98)
         else:
             rews = rew_dev.as_subclass(DeviceArray)
-
-        if done and self.autoreset:
-            self.reset()  # like the reference: obs is post-reset, infos pre-reset (vec_env.py:102-107)
-
-        terminated = self._all_false.copy()
-        truncated = self._all_true.copy() if done else self._all_false.copy()
-        return self._observation(), rews, terminated, truncated, infos
+        obs = self.reset()[0] if done and self.autoreset else self._observation()
+        return obs, rews, self._all_false.copy(), (self._all_true if done else self._all_false).copy(), infos
 
     def reset(self, seed: Optional[int] = None, options: Optional[dict] = None) -> Tuple[DeviceArray, dict]:
         self.step_idx = 0

@@ -359,6 +359,32 @@ def test_wheat_breed_gym_on_device_equals_oracle(small):  # breeding_programs_en
             assert np.array_equal(p[..., 0], p[..., 1])  # every kept plant is a doubled haploid
 
 
+def test_wheat_breed_gym_bit_planes_equal_byte_rows_on_device(small):
+    """the wheat generation on bit planes (the default) against the byte-layout route, both on the device, at a size
+    where the doubled haploids' GEBV takes the matrix-core pass (T = 3) as well as the fused one (T = 1)"""
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+    from breedgym_amd.vector.breeding_programs_env import WheatBreedGym
+
+    for T in (1, 3):
+        gm = synthetic_genetic_map(2000, n_chr=5, n_traits=T, seed=3)
+        geno = synthetic_genotypes(50, 2000, seed=4)
+        kw = dict(num_envs=3, initial_population=geno, individual_per_gen=20, genetic_map=gm, num_generations=3,
+                  reward_shaping=True)
+        wb = WheatBreedGym(VecBreedGym(storage="bits", **kw), n_lines=12, plant_per_line=30, k_per_line=3)
+        wy = WheatBreedGym(VecBreedGym(storage="bytes", **kw), n_lines=12, plant_per_line=30, k_per_line=3)
+        wb.reset(seed=6)
+        wy.reset(seed=6)
+        srng = np.random.default_rng(1)
+        for step in range(4):
+            scores = srng.standard_normal((3, 12, 12)).astype(np.float32)
+            pb, rb, _, tb, ib = wb.step(scores)
+            py, ry, _, ty, iy = wy.step(scores)
+            assert np.array_equal(u8(pb), u8(py)), (T, step)
+            assert gebv_close(np.asarray(ib["GEBV"]), np.asarray(iy["GEBV"], np.float64)) and np.allclose(rb, ry, rtol=1e-5)
+            assert np.array_equal(wb.simulator.random_key, wy.simulator.random_key)
+
+
 # ---- sharding windows: N shards compute what one device would (SURVEY.md 8e) -----------------------------
 
 

@@ -358,6 +358,27 @@ def test_wheat_breed_gym(data):
         WheatBreedGym(env, n_lines=2, plant_per_line=5, k_per_line=2)  # 4 plants < individual_per_gen
 
 
+@pytest.mark.parametrize("observations", ["eager", "lazy"])
+def test_wheat_breed_gym_bit_planes_equal_byte_rows(data, observations):
+    """The wheat generation on bit planes (storage="bits", the default) makes the plants the byte-layout route makes."""
+    from breedgym_amd.vector.breeding_programs_env import WheatBreedGym
+
+    kw = dict(num_envs=2, individual_per_gen=10, num_generations=3, reward_shaping=True)
+    wb = WheatBreedGym(make_vec(data, storage="bits", observations=observations, **kw), n_lines=6, plant_per_line=5, k_per_line=2)
+    wy = WheatBreedGym(make_vec(data, storage="bytes", **kw), n_lines=6, plant_per_line=5, k_per_line=2)
+    wb.reset(seed=4)
+    wy.reset(seed=4)
+    srng = np.random.default_rng(0)
+    for step in range(4):
+        scores = srng.standard_normal((2, 6, 6)).astype(np.float32)
+        pb, rb, _, tb, ib = wb.step(scores)
+        py, ry, _, ty, iy = wy.step(scores)
+        assert np.array_equal(np.asarray(pb), np.asarray(py)), step
+        assert np.allclose(np.asarray(ib["GEBV"]), np.asarray(iy["GEBV"]), rtol=1e-6) and np.allclose(rb, ry, rtol=1e-6)
+        assert np.array_equal(tb, ty)
+        assert np.array_equal(wb.simulator.random_key, wy.simulator.random_key)
+
+
 def test_simplified_and_kbest_env(data):  # reference tests/test_wrappers.py:7-70
     from breedgym_amd.wrappers import KBestBreedGym, SimplifiedBreedGym
 
