@@ -117,6 +117,7 @@ SIGNATURES = {
     "bh_packed_pitch": (_i64, [_vp]),
     "bh_pack": (_int, [_vp, _vp, _i64, _vp]),
     "bh_cross_packed": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _u32p, _int, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "bh_hint_next_cross": (_int, [_vp, _i64, _i64, _int]),
     "bh_step_bind": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64]),
     "bh_step": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _u32p, _int]),
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),

@@ -525,7 +525,20 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // (bit-plane rows: the pass over the packed offspring, gebv_bits.h)
     // one or two traits leave the stream only where the long-row stream takes over (many long bit-plane rows
     // next to four-wave mask groups): elsewhere the digit products inside the stream are cheaper than a pass
-    const bool long_stream = packed && (!c->prefetch || mask_waves_for_runahead(c, B) == 4) && long_row_turns(c, rows) > 1;
+    // the masks made ahead are for the batch the NEXT call will have: the same as this one unless the caller said otherwise
+    // (bh_hint_next_cross: a breeding scheme that alternates 200 crosses with 20,000 doubled haploids)
+    int64_t Bn = B;
+    bool dhn = dh;
+    KeyWindow kwn = kw;
+    if (c->hint.valid) {
+      c->hint.valid = false;
+      if (c->crosses_total == 0 && c->envs_total == 0) {  // (with a sharding window set the hint is ignored)
+        Bn = (c->hint.rng_mode & BH_RNG_INDEPENDENT) ? c->hint.n_envs * c->hint.n_out : c->hint.n_out;
+        dhn = (c->hint.rng_mode & BH_RNG_DOUBLE_HAPLOID) != 0;
+        kwn = {0, Bn};
+      }
+    }
+    const bool long_stream = packed && (!c->prefetch || mask_waves_for_runahead(c, Bn) == 4) && long_row_turns(c, rows) > 1;
     const bool mfma_after =
         d_gebv && (packed ? (c->T >= kMfmaGebvMinTraits ? use_bits_gebv(c, rows) : long_stream) : use_mfma_gebv(c, rows));
     // mutation flips alleles after the crossover: the GEBV (and the reward) must see the mutated rows, so they
@@ -536,14 +549,14 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     // run ahead: the next generation's masks need only the advanced key and the batch size, so
     // the same launch makes them (mask role) while it streams this generation (row role)
     // (beyond kLdsMaskMaxMarkers only the long-row launch can carry the mask role: it keeps no site words in LDS)
-    const bool run_ahead = c->prefetch && (packed || row_waves_for(c, rows) == 1) &&
+    const bool run_ahead = c->prefetch && Bn > 0 && (packed || row_waves_for(c, rows) == 1) &&
                            (c->M <= kLdsMaskMaxMarkers || long_stream);
     bh::MaskParams mp{};
     int mw = 1;
     if (run_ahead) {
-      if (int rc = ensure_z(c, 1 - buf, B * 16 * c->nw)) return rc;
-      mw = mask_waves_for_runahead(c, B);
-      mp = mask_params(c, 1 - buf, nk.x, nk.y, B, mw, dh, kw);
+      if (int rc = ensure_z(c, 1 - buf, Bn * 16 * c->nw)) return rc;
+      mw = mask_waves_for_runahead(c, Bn);
+      mp = mask_params(c, 1 - buf, nk.x, nk.y, Bn, mw, dhn, kwn);
     }
     const bool wide = rows >= 4096;  // else one row per wave: more waves in flight
     // the per-env maximum comes out of the same launch when the GEBV does: every row wave notes its value
@@ -627,10 +640,10 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       c->pf.buf = 1 - buf;
       c->pf.key0 = nk.x;
       c->pf.key1 = nk.y;
-      c->pf.B = B;
-      c->pf.dh = dh;
-      c->pf.off = kw.off;
-      c->pf.total = kw.total;
+      c->pf.B = Bn;
+      c->pf.dh = dhn;
+      c->pf.off = kwn.off;
+      c->pf.total = kwn.total;
     }
     if (mutate)
       if (int rc2 = mutate_rows(c, sim_key[0], sim_key[1], nkeys, kw, B, dh, shared, rows, n_out, d_out_packed, d_out_bytes))
@@ -676,6 +689,17 @@ int bh_cross_packed(bh_ctx *c, const uint16_t *d_pool, int64_t n_envs, int64_t p
                     float *d_gebv, float *d_reward, float *d_reward_next, int64_t reward_pitch) {
   return cross_impl(c, "bh_cross_packed", true, d_pool, n_envs, pool_rows, d_idx, n_out, sim_key, rng_mode,
                     d_out_bytes, d_out_packed, d_gebv, d_reward, d_reward_next, reward_pitch);
+}
+
+int bh_hint_next_cross(bh_ctx *c, int64_t n_envs, int64_t n_out, int rng_mode) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  if (n_envs < 0 || n_out < 0 || rng_mode < 0 || rng_mode > (BH_RNG_INDEPENDENT | BH_RNG_DOUBLE_HAPLOID))
+    return fail(BH_ERR_BAD_ARG, "bh_hint_next_cross: bad arguments");
+  c->hint.valid = true;
+  c->hint.n_envs = n_envs;
+  c->hint.n_out = n_out;
+  c->hint.rng_mode = rng_mode;
+  return BH_OK;
 }
 
 int bh_step_bind(bh_ctx *c, int64_t n_envs, int64_t n_out, int64_t depth, void *const *d_state, void *const *d_obs,

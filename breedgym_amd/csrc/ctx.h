@@ -78,6 +78,11 @@ struct bh_ctx {
     bool dh = false;
     int64_t off = 0, total = 0;
   } pf;
+  struct {  // bh_hint_next_cross: what the NEXT bh_cross* call will be, where it differs from this one
+    bool valid = false;
+    int64_t n_envs = 0, n_out = 0;
+    int rng_mode = 0;
+  } hint;
   int last_buf = 1;
   // fixed-point marker effects for the int8-MFMA GEBV: one pack per group of <= 10 traits
   std::vector<void *> d_Bpack;  // bh::i32x4 rows (gebv_mfma.h)

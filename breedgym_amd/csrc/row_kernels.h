@@ -296,6 +296,7 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     rk11 = __builtin_amdgcn_readlane(rw, 3);
   }
   const KeySched ka = key_sched(rk00, rk01), kb = key_sched(rk10, rk11);
+  const bool one_gamete = p.dh != 0;  // wave-uniform
   if constexpr (SYNC == SYNC_COUNTER) {
     if (iter > 0) {  // the previous cross's prefix pass must be through with the site words
       bool ok = false;
@@ -327,13 +328,25 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
 #define BH_TRIP(T_, J_, TA_, TB_, C1_)                                                                              \
   {                                                                                                                 \
     uint32_t a0 = (J_) + rk00, a1 = (C1_) + rk01, b0 = (J_) + rk10, b1 = (C1_) + rk11;                              \
-    asm volatile(BH_TFA BH_TFB                                                                                      \
-                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                           \
-                 : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
-                   "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),              \
-                   "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                         \
-    uint64_t sA0 = __ballot(a0 < (TA_)), sB0 = __ballot(a1 < (TB_));                                                \
-    uint64_t sA1 = __ballot(b0 < (TA_)), sB1 = __ballot(b1 < (TB_));                                                \
+    uint64_t sA0, sB0, sA1, sB1;                                                                                    \
+    if (one_gamete) { /* doubled haploids: both slots are the ONE gamete of keys[1 + c] -- one chain, not two */     \
+      asm volatile(BH_TFA                                                                                           \
+                   : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                         \
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),            \
+                     "s"(ka.w[6]), "s"(ka.w[7]));                                                                   \
+      sA0 = sA1 = __ballot(a0 < (TA_));                                                                             \
+      sB0 = sB1 = __ballot(a1 < (TB_));                                                                             \
+    } else {                                                                                                        \
+      asm volatile(BH_TFA BH_TFB                                                                                    \
+                   : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                         \
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),            \
+                     "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),            \
+                     "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                       \
+      sA0 = __ballot(a0 < (TA_));                                                                                   \
+      sB0 = __ballot(a1 < (TB_));                                                                                   \
+      sA1 = __ballot(b0 < (TA_));                                                                                   \
+      sB1 = __ballot(b1 < (TB_));                                                                                   \
+    }                                                                                                               \
     if (p.alwA) {                                                                                                   \
       const uint64_t xa = p.alwA[(T_)], xb = p.alwB[(T_)];                                                          \
       sA0 |= xa;                                                                                                    \
@@ -355,19 +368,35 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
 #define BH_TRIP_P(T_, J_, TA_, TB_, C1_)                                                                            \
   {                                                                                                                 \
     uint32_t a0 = rk00, a1 = (J_) + rk01, b0 = rk10, b1 = (J_) + rk11;                                              \
-    asm volatile(BH_TFA BH_TFB                                                                                      \
-                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                           \
-                 : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
-                   "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),              \
-                   "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                         \
     uint32_t c0 = rk00, c1 = (C1_) + rk01, d0 = rk10, d1 = (C1_) + rk11;                                            \
-    asm volatile(BH_TFA BH_TFB                                                                                      \
-                 : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)                                                           \
-                 : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),              \
-                   "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),              \
-                   "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                         \
-    uint64_t sA0 = __ballot((a0 ^ a1) < (TA_)), sB0 = __ballot((c0 ^ c1) < (TB_));                                  \
-    uint64_t sA1 = __ballot((b0 ^ b1) < (TA_)), sB1 = __ballot((d0 ^ d1) < (TB_));                                  \
+    uint64_t sA0, sB0, sA1, sB1;                                                                                    \
+    if (one_gamete) {                                                                                               \
+      asm volatile(BH_TFA                                                                                           \
+                   : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                         \
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),            \
+                     "s"(ka.w[6]), "s"(ka.w[7]));                                                                   \
+      asm volatile(BH_TFA                                                                                           \
+                   : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)                                                         \
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),            \
+                     "s"(ka.w[6]), "s"(ka.w[7]));                                                                   \
+      sA0 = sA1 = __ballot((a0 ^ a1) < (TA_));                                                                      \
+      sB0 = sB1 = __ballot((c0 ^ c1) < (TB_));                                                                      \
+    } else {                                                                                                        \
+      asm volatile(BH_TFA BH_TFB                                                                                    \
+                   : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                         \
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),            \
+                     "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),            \
+                     "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                       \
+      asm volatile(BH_TFA BH_TFB                                                                                    \
+                   : "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1)                                                         \
+                   : "s"(ka.w[0]), "s"(ka.w[1]), "s"(ka.w[2]), "s"(ka.w[3]), "s"(ka.w[4]), "s"(ka.w[5]),            \
+                     "s"(ka.w[6]), "s"(ka.w[7]), "s"(kb.w[0]), "s"(kb.w[1]), "s"(kb.w[2]), "s"(kb.w[3]),            \
+                     "s"(kb.w[4]), "s"(kb.w[5]), "s"(kb.w[6]), "s"(kb.w[7]));                                       \
+      sA0 = __ballot((a0 ^ a1) < (TA_));                                                                            \
+      sB0 = __ballot((c0 ^ c1) < (TB_));                                                                            \
+      sA1 = __ballot((b0 ^ b1) < (TA_));                                                                            \
+      sB1 = __ballot((d0 ^ d1) < (TB_));                                                                            \
+    }                                                                                                               \
     if (p.alwA) {                                                                                                   \
       const uint64_t xa = p.alwA[(T_)], xb = p.alwB[(T_)];                                                          \
       sA0 |= xa;                                                                                                    \

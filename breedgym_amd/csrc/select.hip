@@ -171,8 +171,11 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
                                hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
     c->big_lds_set = true;
   }
-  if (n > kTopkChunk) {
-    // long vectors: radix select of the k-th key, then sort only the k winners in LDS
+  // long vectors: radix select of the k-th key, then sort only the k winners in LDS -- one workgroup per row.  Where
+  // one more level of chunk sorts is enough (few winners: PairScores' 200 of 40,000 pair scores) the chunk route
+  // below spreads a row over several workgroups and is five times faster (21 against 119 us for 4 x 40,000 -> 200)
+  const int64_t chunks0 = (n + kTopkChunk - 1) / kTopkChunk;
+  if (n > kTopkChunk && chunks0 * k > kTopkChunk) {
     bh::TopkSelectParams q{};
     q.scores = d_scores;
     q.out_idx = d_idx_out;

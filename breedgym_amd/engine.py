@@ -550,6 +550,11 @@ class HipEngine(EngineBase):
         """One batch of crosses cut row-wise over several engines: cross b here is cross cross_offset + b."""
         _lib.check(self._L.bh_set_cross_window(self._h, int(cross_offset), int(crosses_total)))
 
+    def hint_next_cross(self, n_envs: int, n_out: int, rng_mode: int) -> None:
+        """Say what the cross call AFTER the next one will be (bh_hint_next_cross): the next call's launch then makes
+        that call's crossover masks, not a repeat of its own."""
+        _lib.check(self._L.bh_hint_next_cross(self._h, int(n_envs), int(n_out), int(rng_mode)))
+
     def set_mask_prefetch(self, enable: bool) -> None:
         """Run-ahead of the next generation's crossover masks on a side stream (default on)."""
         _lib.check(self._L.bh_set_mask_prefetch(self._h, int(bool(enable))))

@@ -59,6 +59,20 @@ class WheatBreedGym(VectorWrapper):
         env.populations, _ = sim.select(kept, k=self.individual_per_gen)
         return env.get_info()
 
+    def _index_tables(self, E, L, P, K, n, dev):
+        """What does not change from step to step: every plant's F1 (twice: a doubled haploid has one parent), and the
+        first row of every line / env in the flat row numbering the gathers use."""
+        key = (E, L, P, K, n, str(dev))
+        if getattr(self, "_ix_key", None) != key:
+            one = torch.arange(L, dtype=torch.int32, device=dev).repeat_interleave(P)
+            self._ix = {
+                "dh": one.repeat(E).reshape(E, L * P, 1).expand(-1, -1, 2).contiguous(),
+                "line0": (torch.arange(E * L, dtype=torch.int32, device=dev) * P).unsqueeze(1),
+                "env0": (torch.arange(E, dtype=torch.int32, device=dev) * (L * K)).unsqueeze(1),
+            }
+            self._ix_key = key
+        return self._ix
+
     def _generation_on_bit_planes(self, low):
         """The same generation with every population as bit planes (``storage="bits"``, the default): the 80,000
         doubled haploids of 4 envs x 200 lines x 100 plants are 0.2 GB instead of 1.6 GB, their GEBV comes out of the
@@ -67,21 +81,26 @@ class WheatBreedGym(VectorWrapper):
         env, sim = self.env, self.simulator
         eng, E, L, P, K, n = sim.engine, self.num_envs, self.n_lines, self.plant_per_line, self.k_per_line, self.individual_per_gen
         dev, T = eng.device, eng.n_traits
+        ix = self._index_tables(E, L, P, K, n, dev)
+        hint = getattr(eng, "hint_next_cross", None)  # the launches alternate two batch shapes: say which comes next,
+        dh_mode = env._rng_mode | _lib.RNG_DOUBLE_HAPLOID  # so that each makes the other's crossover masks ahead
         f1 = eng.empty_packed(E * L)
+        if hint:
+            hint(E, L * P, dh_mode)
         sim.cross_indexed_packed(env._prows, E, env._n, low, L, f1, None, None, env._rng_mode)
         # every F1 gives P doubled haploids (Simulator.double_haploid's key plumbing: one key per plant)
-        one = torch.arange(L, dtype=torch.int32, device=dev).repeat_interleave(P)
-        idx = one.repeat(E).reshape(E, L * P, 1).expand(-1, -1, 2).contiguous()
         dh, g = eng.empty_packed(E * L * P), eng.empty((E * L, P, T), torch.float32)
-        sim.cross_indexed_packed(f1, E, L, idx, L * P, dh, None, g, env._rng_mode | _lib.RNG_DOUBLE_HAPLOID)
+        if hint:
+            hint(E, L, env._rng_mode)
+        sim.cross_indexed_packed(f1, E, L, ix["dh"], L * P, dh, None, g, dh_mode)
         # the K best plants of every line by the conventional index (the sum of the GEBVs over traits), best first
-        best = eng.topk(g.sum(dim=-1), K).to(torch.int64)  # (E * L, K)
-        flat = (best + torch.arange(E * L, device=dev).unsqueeze(1) * P).to(torch.int32).reshape(-1).contiguous()
+        best = eng.topk(g.sum(dim=-1) if T > 1 else g.reshape(E * L, P), K)  # (E * L, K) int32
+        flat = (best + ix["line0"]).reshape(-1)
         kept, gk = eng.empty_packed(E * L * K), eng.empty((E, L * K, T), torch.float32)
         eng.gather_packed(dh, flat, E * L * K, kept, None, gk)
         # ... and the n best of an env's kept plants are the next population
-        best = eng.topk(gk.sum(dim=-1), n).to(torch.int64)  # (E, n)
-        flat = (best + torch.arange(E, device=dev).unsqueeze(1) * (L * K)).to(torch.int32).reshape(-1).contiguous()
+        best = eng.topk(gk.sum(dim=-1) if T > 1 else gk.reshape(E, L * K), n)  # (E, n)
+        flat = (best + ix["env0"]).reshape(-1)
         newp, gn = eng.empty_packed(E * n), eng.empty((E, n, T), torch.float32)
         newb = eng.empty_population(E * n) if env.observations == "eager" else None
         eng.gather_packed(kept, flat, E * n, newp, newb, gn)

@@ -192,6 +192,13 @@ int bh_cross_packed(bh_ctx *ctx, const uint16_t *d_pool, int64_t n_envs, int64_t
                     const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
                     uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv, float *d_reward,
                     float *d_reward_next, int64_t reward_pitch);
+/* The masks a launch makes ahead are those of a call of the same shape -- right for a step loop.  A scheme that
+ * alternates shapes (breeding_programs_env.py:47-56: 200 crosses, then 20,000 doubled haploids, then 200 crosses ...)
+ * says before a call what the call AFTER it will be, and that call finds its masks made: n_envs, n_out and rng_mode as
+ * they will be passed.  One hint serves one call; without one the next call is assumed to repeat this one; a wrong
+ * hint costs time, never results.  Ignored while a sharding window is set. */
+int bh_hint_next_cross(bh_ctx *ctx, int64_t n_envs, int64_t n_out, int rng_mode);
+
 /* `VecBreedGym.step` (vec_env.py:79-107) on output blocks bound once: what a step loop repeats -- four output
  * pointers, sizes, pitches -- is handed over once, and a step is bh_cross_packed with the few arguments that change.
  * The caller owns the blocks and decides which one a step writes (it alone knows which of them somebody still
