@@ -171,10 +171,15 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
                                hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8));
     c->big_lds_set = true;
   }
-  // long vectors: radix select of the k-th key, then sort only the k winners in LDS -- one workgroup per row.  Where
-  // one more level of chunk sorts is enough (few winners: PairScores' 200 of 40,000 pair scores) the chunk route
-  // below spreads a row over several workgroups and is five times faster (21 against 119 us for 4 x 40,000 -> 200)
-  const int64_t chunks0 = (n + kTopkChunk - 1) / kTopkChunk;
+  // Long vectors.  One route: radix select of the k-th key, then a sort of the k winners in LDS -- one workgroup per
+  // row, whatever its length.  The other: chunk sorts in levels (below), a row spread over many workgroups; worth it
+  // where two levels are enough, i.e. few winners (PairScores' 200 of 40,000 pair scores).  A bitonic sort costs
+  // P log^2 P, so those chunks are kept short: ~8 k candidates each, 2048 at least (4 x 40,000 -> 200: 119 us by
+  // select, 158 us with 16384-candidate chunks, ~20 us with 4096-candidate ones)
+  int64_t cs = 2048;
+  while (cs < 8 * k && cs < kTopkChunk) cs <<= 1;
+  if (n <= kTopkChunk) cs = kTopkChunk;  // a row one workgroup sorts whole
+  const int64_t chunks0 = (n + cs - 1) / cs;
   if (n > kTopkChunk && chunks0 * k > kTopkChunk) {
     bh::TopkSelectParams q{};
     q.scores = d_scores;
@@ -193,15 +198,15 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
     BH_HIP(hipGetLastError());
     return BH_OK;
   }
-  // level 0 reads the caller's scores; every level keeps the best kk of each chunk of <= 16384
+  // level 0 reads the caller's scores; every level keeps the best kk of each chunk of <= cs
   // candidates, until one chunk is left.  top-k of a union = top-k of the parts' top-k.
   const float *in_s = d_scores;
   const int32_t *in_i = nullptr;
   int64_t n_in = n;
   int flip = 0;
   for (;;) {
-    const int64_t chunks = (n_in + kTopkChunk - 1) / kTopkChunk;
-    const int64_t chunk = chunks == 1 ? n_in : kTopkChunk;
+    const int64_t chunks = (n_in + cs - 1) / cs;
+    const int64_t chunk = chunks == 1 ? n_in : cs;
     const int64_t kk = std::min<int64_t>(k, chunk);
     int64_t P = 2;
     while (P < chunk) P <<= 1;
