@@ -103,6 +103,18 @@ int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
 constexpr int64_t kLdsMaskMaxMarkers = (int64_t)1 << 18;
 int ensure_sites(bh_ctx *c, int64_t B);
 
+// site words -> crossover masks (mask_stream.h): a wave per cross when there are many, four when there are few
+int launch_mask_finish(bh_ctx *c, const bh::MaskParams &m) {
+  if (m.n_rows <= 0) return BH_OK;
+  if (m.n_rows < 4096 && m.nw >= 256)
+    hipLaunchKernelGGL(bh::mask_finish4_kernel, dim3((unsigned)m.n_rows), dim3(256), 0, c->stream, m);
+  else
+    hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((m.n_rows + 3) / 4)), dim3(256), 0, c->stream, m);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_finish_kernel launch: %s", hipGetErrorString(e));
+  return BH_OK;
+}
+
 // crossover masks of B crosses keyed off `key` into d_Z[buf], in stream order (not overlapped)
 int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bool dh, KeyWindow kw) {
   if (c->M > kLdsMaskMaxMarkers) {
@@ -115,10 +127,9 @@ int launch_masks(bh_ctx *c, int buf, uint32_t key0, uint32_t key1, int64_t B, bo
     const int64_t tiles = (c->nwh + bh::kSiteTileTrips - 1) / bh::kSiteTileTrips;
     if (B * tiles > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "too many crosses x markers for one mask launch");
     hipLaunchKernelGGL(bh::mask_sites_kernel, dim3((unsigned)(B * tiles)), dim3(256), 0, c->stream, m);
-    hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, c->stream, m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_sites_kernel launch: %s", hipGetErrorString(e));
-    return BH_OK;
+    return launch_mask_finish(c, m);
   }
   const int waves = waves_for(c);
   const bh::MaskParams m = mask_params(c, buf, key0, key1, B, waves, dh, kw);
@@ -197,11 +208,7 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
-  if (mp.sites) {  // site words -> crossover masks, one wave per keyed cross
-    hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((mp.n_rows + 3) / 4)), dim3(256), 0, c->stream, mp);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_finish_kernel launch: %s", hipGetErrorString(e));
-  }
+  if (mp.sites) return launch_mask_finish(c, mp);  // site words -> crossover masks
   return BH_OK;
 }
 
@@ -214,12 +221,9 @@ int launch_plong(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
                      dim3(64 * (4 + kLongMaskWaves)), 0, c->stream, rp, mp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_long_kernel launch: %s", hipGetErrorString(e));
-  // site words -> masks, one wave per keyed cross, in stream order (a stream of its own beside the GEBV pass
-  // that follows was measured: 811 against 818 us per step at 8192 x 100k -- both want the same memory system)
-  hipLaunchKernelGGL(bh::mask_finish_kernel, dim3((unsigned)((mp.n_rows + 3) / 4)), dim3(256), 0, c->stream, mp);
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(BH_ERR_HIP, "mask_finish_kernel launch: %s", hipGetErrorString(e));
-  return BH_OK;
+  // site words -> masks, in stream order (a stream of its own beside the GEBV pass that follows was measured: 811
+  // against 818 us per step at 8192 x 100k -- both want the same memory system)
+  return launch_mask_finish(c, mp);
 }
 
 template <int MW, int R>
@@ -460,6 +464,31 @@ extern "C" {
 
 // bh_cross and bh_cross_packed: `packed` selects the layout of the pool and of d_out_packed;
 // d_out_bytes is the byte-layout offspring (required unless packed, optional when packed).
+//
+// Which kernels a call becomes.  M markers, rows = n_envs * n_out offspring, B = crosses that own keys (n_out with
+// shared keys, rows otherwise), Bn = B of the NEXT call (= B unless bh_hint_next_cross said otherwise), T traits.
+//
+//   this generation's masks   made ahead by the previous call's launch (key, B, double-haploid flag and key window all
+//                             as predicted)  -> nothing to do;  otherwise launch_masks in stream order: mask_kernel<1>
+//                             (M <= 16384), mask_kernel<4> (M <= 2^18), mask_sites_kernel + mask_finish_kernel (beyond)
+//   long_stream               packed && rows >= 8192 && M > 16384 && the mask role would take four waves per cross
+//                             (Bn <= 512 or M > 16384) or there is no run-ahead
+//   GEBV (when asked for)     fused in the row role: T <= 8, no mutation, and not `mfma_after`;
+//                             mfma_after (a matrix-core pass behind the launch): bit planes: T >= 3 and rows >= 32, or
+//                             T <= 2 on the long_stream; byte layout: T >= 3 and rows >= 32;
+//                             otherwise (T > 8 without MFMA, mutation): f64 passes over the offspring
+//   run_ahead (mask role in   prefetch on, Bn > 0, bit planes or one-wave byte rows (not: a few very long byte rows,
+//   the same launch)          four waves each), and M <= 2^18 unless long_stream (beyond, only that launch's mask role
+//                             keeps no site words in LDS)
+//   the launch, bit planes    run_ahead: mw = 1 (Bn > 512 and M <= 16384): packed_cross_kernel<TT, 1, R>;  mw = 4 and
+//                             long_stream without fused GEBV: packed_long_kernel<1, 8> (LDS-DMA row stream, stream-per-
+//                             lane mask role) + mask_finish_kernel;  else packed_cross_kernel<TT, 4, R> (a deferred
+//                             founder draw of <= 1024 rows rides on it);  R = 2 rows per wave from 4096 rows on.
+//                             no run_ahead: packed_row_kernel<TT, MODE_CROSS, R> (long rows in turns: its DMA stream)
+//   the launch, byte layout   run_ahead: cross_kernel<TT, mw, R, LONG>;  else row_kernel<W, TT, MODE_CROSS, R, LONG>
+//                             (W = 4 waves per row for fewer than 2048 rows of more than 16384 markers)
+//   behind the launch         mutation: mutation_sites_kernel + mutation_apply_kernel;  GEBV passes as above;  reward:
+//                             noted inside the launch when the GEBV is fused, else reward_max_kernel
 static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_pool, int64_t n_envs,
                       int64_t pool_rows, const int32_t *d_idx, int64_t n_out, uint32_t sim_key[2], int rng_mode,
                       uint8_t *d_out_bytes, uint16_t *d_out_packed, float *d_gebv, float *d_reward,
@@ -592,7 +621,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
           rc = wide ? launch_pcross_mw<1, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))
                     : launch_pcross_mw<1, 1>(c, p, mp, tt_for(tcount));
         else if (turns > 1) {
-          if (int rc2 = ensure_sites(c, B)) return rc2;
+          if (int rc2 = ensure_sites(c, Bn)) return rc2;  // the site words of the batch the masks are made for
           mp.sites = c->d_S;
           mp.spitch = c->nwh + 1;
           rc = launch_plong(c, p, mp);

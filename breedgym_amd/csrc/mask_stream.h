@@ -299,4 +299,67 @@ __global__ __launch_bounds__(256) void mask_finish_kernel(const MaskParams p) {
   }
 }
 
+// The same phase B with FOUR waves per cross, for launches with few keyed crosses (BASELINE configs[2]: 2048): one
+// wave per cross walks a 100k-marker row in seven dependent round trips to memory (43 us for 2048 crosses: latency, not
+// bytes).  Here every wave takes a quarter of the row: it first reads its quarter once for nothing but the parity of
+// its site bits (all loads in flight together), the four parities meet in LDS -- the crossover state a quarter starts
+// in is the XOR of the quarters before it -- and then it runs the prefix-XOR over its quarter from that state (the
+// second read comes out of the L2).  Two round trips instead of seven, four times the waves.
+__global__ __launch_bounds__(256) void mask_finish4_kernel(const MaskParams p) {
+  __shared__ uint32_t par[4][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x;  // grid = n_rows
+  const uint64_t *S = p.sites + (int64_t)c * 4 * p.spitch;
+  uint8_t *Z = p.Z + (int64_t)c * p.zpitch;
+  const int quarter = ((p.nw + 255) / 256) * 64;  // words per wave, a multiple of 64
+  const int w_lo = wv * quarter, w_hi = min(p.nw, w_lo + quarter);
+  {
+    uint32_t q0 = 0, q1 = 0;
+    for (int w = w_lo + lane; w < w_hi; w += 64) {
+      q0 ^= (uint32_t)__popcll(site_word_planar(S, p.spitch, 0, w, p.half));
+      q1 ^= (uint32_t)__popcll(site_word_planar(S, p.spitch, 1, w, p.half));
+    }
+    const uint32_t t0 = (uint32_t)__popcll(__ballot(q0 & 1u)) & 1u, t1 = (uint32_t)__popcll(__ballot(q1 & 1u)) & 1u;
+    if (lane == 0) {
+      par[wv][0] = t0;
+      par[wv][1] = t1;
+    }
+  }
+  __syncthreads();
+  uint32_t carry0 = 0, carry1 = 0;
+  for (int k = 0; k < wv; ++k) {
+    carry0 ^= par[k][0];
+    carry1 ^= par[k][1];
+  }
+  const uint64_t below = (1ull << lane) - 1ull;
+  constexpr int U = 4;
+  for (int w0 = w_lo; w0 < w_hi; w0 += 64 * U) {
+    uint64_t s0[U], s1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = w0 + 64 * u + lane;
+      s0[u] = w < w_hi ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
+      s1[u] = w < w_hi ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int w = w0 + 64 * u + lane;
+      uint64_t x0 = prefix_xor64(s0[u]), x1 = prefix_xor64(s1[u]);
+      const uint64_t par0 = __ballot((x0 >> 63) != 0), par1 = __ballot((x1 >> 63) != 0);
+      if ((__popcll(par0 & below) & 1u) ^ carry0) x0 = ~x0;
+      if ((__popcll(par1 & below) & 1u) ^ carry1) x1 = ~x1;
+      carry0 ^= __popcll(par0) & 1u;
+      carry1 ^= __popcll(par1) & 1u;
+      if (w < w_hi) {
+        uint4 z;
+        z.x = spread16((uint32_t)x0 & 0xffffu) | (spread16((uint32_t)x1 & 0xffffu) << 1);
+        z.y = spread16((uint32_t)x0 >> 16) | (spread16((uint32_t)x1 >> 16) << 1);
+        z.z = spread16((uint32_t)(x0 >> 32) & 0xffffu) | (spread16((uint32_t)(x1 >> 32) & 0xffffu) << 1);
+        z.w = spread16((uint32_t)(x0 >> 48)) | (spread16((uint32_t)(x1 >> 48)) << 1);
+        *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
+      }
+    }
+  }
+}
+
 }  // namespace bh
