@@ -280,7 +280,7 @@ def committed_traffic(kernel_prefix):
         if name.startswith(want):
             return b, (f"measured by this run: child passes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
                        f"(separate), mean of {n} launches of {name}, 2 x FETCH_SIZE + WRITE_SIZE in KiB")
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         f = ROOT / "profiles" / name
         if not f.exists():
             continue
@@ -321,13 +321,13 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
         kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False)
         nbytes = cross_bytes(M, E * n, n, "bits", obs)
         r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
-             "roofline": roofline_of("packed_long_kernel<1,8> + mask_finish_kernel (long rows: four row waves stream rows "
+             "roofline": roofline_of("packed_long_kernel<1,8> + mask_finish4_kernel (long rows: four row waves stream rows "
                                      "without GEBV, eight mask waves draw the next generation's sites one gamete stream "
                                      "per lane -- 2048 keyed crosses x 100k markers of Threefry; then site words -> masks)",
                                      nbytes + 2 * 4 * n * (M // 128 + 2) * 8, kms,  # + site words written and read back
                                      api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
              # both kernels of the timed pair; the PMC passes are of the eager configuration
-             "traffic": (committed_traffic("packed_long_kernel")[0] or 0) + (committed_traffic("mask_finish_kernel")[0] or 0)
+             "traffic": (committed_traffic("packed_long_kernel")[0] or 0) + (committed_traffic("mask_finish")[0] or 0)
                         if obs == "eager" and committed_traffic("packed_long_kernel")[0] else None,
              "traffic_source": committed_traffic("packed_long_kernel")[1] if obs == "eager" else None,
              "gebv_pass_ms": kms_all - kms,

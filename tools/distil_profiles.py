@@ -1,14 +1,17 @@
-"""Distil gpurun_out/prof_r02/ (tools/collect_profiles_r02.sh, run on the GPU box) into the committed files under
-profiles/: r02_kernel_stats_{c2,c3,c5}.csv, r02_pmc.json and r02_pmc_traffic.json (per-kernel HBM-side bytes per
-launch, corrected as MI355X_MICROARCH.md prescribes; bench.py names it as the source of roofline.traffic)."""
+"""Distil gpurun_out/prof_<round>/ (tools/collect_profiles.sh <round>, run on the GPU box) into the committed files
+under profiles/: <round>_kernel_stats_{c2,c3,c3lazy,c4,c5,wheat}.csv, <round>_pmc.json and <round>_pmc_traffic.json
+(per-kernel memory-side bytes per launch, corrected as MI355X_MICROARCH.md prescribes; bench.py names it as the source of
+roofline.traffic when its own live passes fail).   usage: distil_profiles.py r03"""
 import csv
 import glob
 import json
+import sys
 from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-src, dst = ROOT / "gpurun_out" / "prof_r02", ROOT / "profiles"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src, dst = ROOT / "gpurun_out" / f"prof_{TAG}", ROOT / "profiles"
 
 
 def newest(pattern):
@@ -20,11 +23,11 @@ def short(name):
     return name.split("(")[0].replace("void bh::", "").replace("bh::", "")
 
 
-for cfg in ("c2", "c3", "c3lazy", "c5"):
+for cfg in ("c2", "c3", "c3lazy", "c4", "c5", "wheat"):
     f = newest(f"kt_{cfg}/**/*kernel_stats.csv")
     if f:
         rows = list(csv.DictReader(open(f)))
-        with open(dst / f"r02_kernel_stats_{cfg}.csv", "w", newline="") as o:
+        with open(dst / f"{TAG}_kernel_stats_{cfg}.csv", "w", newline="") as o:
             w = csv.DictWriter(o, fieldnames=rows[0].keys())
             w.writeheader()
             w.writerows(rows)
@@ -49,7 +52,7 @@ def counters(sub):
 
 
 pmc = {f"{kind}_{cfg}": counters(f"{kind}_{cfg}") for cfg in ("c2", "c3", "c5") for kind in ("fetch", "write", "sq")}
-(dst / "r02_pmc.json").write_text(json.dumps(pmc, indent=1, sort_keys=True))
+(dst / f"{TAG}_pmc.json").write_text(json.dumps(pmc, indent=1, sort_keys=True))
 
 # HBM-side bytes per launch: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
 # wide coalesced (16 B/lane) streaming read -> doubled; WRITE_SIZE is exact for 16-B/lane stores.  The 2-byte genotype
@@ -57,14 +60,14 @@ pmc = {f"{kind}_{cfg}": counters(f"{kind}_{cfg}") for cfg in ("c2", "c3", "c5") 
 kernels = []
 for cfg in ("c2", "c3", "c5"):
     for k, d in pmc[f"fetch_{cfg}"].items():
-        if not any(t in k for t in ("packed_cross_kernel", "packed_long_kernel", "mask_finish_kernel", "gebv_bits_kernel", "gebv_finish_kernel", "gebv_mfma_kernel")):
+        if not any(t in k for t in ("packed_cross_kernel", "packed_long_kernel", "mask_finish", "gebv_bits_kernel", "gebv_bytes_kernel", "gebv_finish_kernel", "gebv_mfma_kernel")):
             continue
         fk = d.get("FETCH_SIZE", 0.0)
         wk = pmc[f"write_{cfg}"].get(k, {}).get("WRITE_SIZE", 0.0)
         kernels.append({"config": cfg, "kernel": k, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
                         "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "dispatches": d.get("dispatches")})
-(dst / "r02_pmc_traffic.json").write_text(json.dumps({
-    "correction": "2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (MI355X_MICROARCH.md, HBM); separate --pmc passes",
-    "made_by": "tools/collect_profiles_r02.sh + tools/distil_profiles_r02.py", "kernels": kernels}, indent=1))
+(dst / f"{TAG}_pmc_traffic.json").write_text(json.dumps({
+    "correction": "2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (MI355X_MICROARCH.md, HBM); separate --pmc passes; memory-side bytes: Infinity-Cache hits are counted",
+    "made_by": f"tools/collect_profiles.sh {TAG} + tools/distil_profiles.py {TAG}", "kernels": kernels}, indent=1))
 for k in kernels:
     print(f"{k['config']} {k['kernel'][:50]:50s} {k['hbm_bytes_per_launch']/1e6:10.1f} MB per launch")
