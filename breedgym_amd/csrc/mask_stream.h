@@ -313,11 +313,29 @@ __global__ __launch_bounds__(256) void mask_finish4_kernel(const MaskParams p) {
   uint8_t *Z = p.Z + (int64_t)c * p.zpitch;
   const int quarter = ((p.nw + 255) / 256) * 64;  // words per wave, a multiple of 64
   const int w_lo = wv * quarter, w_hi = min(p.nw, w_lo + quarter);
+  // up to 512 words per quarter (131k markers) the site words stay in registers between the two passes
+  constexpr int KEEP = 8;
+  const bool keep = quarter <= 64 * KEEP;  // uniform
+  uint64_t k0[KEEP], k1[KEEP];
   {
     uint32_t q0 = 0, q1 = 0;
-    for (int w = w_lo + lane; w < w_hi; w += 64) {
-      q0 ^= (uint32_t)__popcll(site_word_planar(S, p.spitch, 0, w, p.half));
-      q1 ^= (uint32_t)__popcll(site_word_planar(S, p.spitch, 1, w, p.half));
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < KEEP; ++u) {
+        const int w = w_lo + 64 * u + lane;
+        k0[u] = w < w_hi ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
+        k1[u] = w < w_hi ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < KEEP; ++u) {
+        q0 ^= (uint32_t)__popcll(k0[u]);
+        q1 ^= (uint32_t)__popcll(k1[u]);
+      }
+    } else {
+      for (int w = w_lo + lane; w < w_hi; w += 64) {
+        q0 ^= (uint32_t)__popcll(site_word_planar(S, p.spitch, 0, w, p.half));
+        q1 ^= (uint32_t)__popcll(site_word_planar(S, p.spitch, 1, w, p.half));
+      }
     }
     const uint32_t t0 = (uint32_t)__popcll(__ballot(q0 & 1u)) & 1u, t1 = (uint32_t)__popcll(__ballot(q1 & 1u)) & 1u;
     if (lane == 0) {
@@ -332,32 +350,38 @@ __global__ __launch_bounds__(256) void mask_finish4_kernel(const MaskParams p) {
     carry1 ^= par[k][1];
   }
   const uint64_t below = (1ull << lane) - 1ull;
-  constexpr int U = 4;
-  for (int w0 = w_lo; w0 < w_hi; w0 += 64 * U) {
-    uint64_t s0[U], s1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int w = w0 + 64 * u + lane;
-      s0[u] = w < w_hi ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
-      s1[u] = w < w_hi ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
+  auto block = [&](int w, uint64_t s0, uint64_t s1) {  // one 64-word block: prefix-XOR, then the interleaved mask words
+    uint64_t x0 = prefix_xor64(s0), x1 = prefix_xor64(s1);
+    const uint64_t par0 = __ballot((x0 >> 63) != 0), par1 = __ballot((x1 >> 63) != 0);
+    if ((__popcll(par0 & below) & 1u) ^ carry0) x0 = ~x0;
+    if ((__popcll(par1 & below) & 1u) ^ carry1) x1 = ~x1;
+    carry0 ^= __popcll(par0) & 1u;
+    carry1 ^= __popcll(par1) & 1u;
+    if (w < w_hi) {
+      uint4 z;
+      z.x = spread16((uint32_t)x0 & 0xffffu) | (spread16((uint32_t)x1 & 0xffffu) << 1);
+      z.y = spread16((uint32_t)x0 >> 16) | (spread16((uint32_t)x1 >> 16) << 1);
+      z.z = spread16((uint32_t)(x0 >> 32) & 0xffffu) | (spread16((uint32_t)(x1 >> 32) & 0xffffu) << 1);
+      z.w = spread16((uint32_t)(x0 >> 48)) | (spread16((uint32_t)(x1 >> 48)) << 1);
+      *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
     }
+  };
+  if (keep) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int w = w0 + 64 * u + lane;
-      uint64_t x0 = prefix_xor64(s0[u]), x1 = prefix_xor64(s1[u]);
-      const uint64_t par0 = __ballot((x0 >> 63) != 0), par1 = __ballot((x1 >> 63) != 0);
-      if ((__popcll(par0 & below) & 1u) ^ carry0) x0 = ~x0;
-      if ((__popcll(par1 & below) & 1u) ^ carry1) x1 = ~x1;
-      carry0 ^= __popcll(par0) & 1u;
-      carry1 ^= __popcll(par1) & 1u;
-      if (w < w_hi) {
-        uint4 z;
-        z.x = spread16((uint32_t)x0 & 0xffffu) | (spread16((uint32_t)x1 & 0xffffu) << 1);
-        z.y = spread16((uint32_t)x0 >> 16) | (spread16((uint32_t)x1 >> 16) << 1);
-        z.z = spread16((uint32_t)(x0 >> 32) & 0xffffu) | (spread16((uint32_t)(x1 >> 32) & 0xffffu) << 1);
-        z.w = spread16((uint32_t)(x0 >> 48)) | (spread16((uint32_t)(x1 >> 48)) << 1);
-        *reinterpret_cast<uint4 *>(Z + 16 * (int64_t)w) = z;
+    for (int u = 0; u < KEEP; ++u)
+      if (w_lo + 64 * u < w_hi) block(w_lo + 64 * u + lane, k0[u], k1[u]);  // uniform
+  } else {
+    constexpr int U = 4;
+    for (int w0 = w_lo; w0 < w_hi; w0 += 64 * U) {
+      uint64_t s0[U], s1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int w = w0 + 64 * u + lane;
+        s0[u] = w < w_hi ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
+        s1[u] = w < w_hi ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) block(w0 + 64 * u + lane, s0[u], s1[u]);
     }
   }
 }

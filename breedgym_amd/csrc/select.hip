@@ -34,14 +34,13 @@ int launch_founders(bh_ctx *c, const bh::FoundersParams &p) {
 
 // ---- the radix sort in HBM (sort_kernels.h) -----------------------------------------------------------------
 struct SortBufs {
-  uint32_t *kA, *kB;
-  int32_t *vA, *vB;
+  uint2 *A, *B;  // (key, value) elements, twice
   uint32_t *hist, *tot, *sub;
   int64_t stride;  // elements per segment in the four arrays
   int32_t nb;      // tiles per segment
 };
 
-// segments one batch sorts side by side: <= 2^25 elements of scratch (0.5 GB), <= 65535 (grid.y)
+// segments one batch sorts side by side: <= 2^25 elements (0.5 GB of scratch), <= 65535 (grid.y)
 int64_t sort_batch(int64_t segs, int64_t N) {
   const int64_t stride = round_up(N, 64);
   return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(segs, 65535), ((int64_t)1 << 25) / stride));
@@ -50,26 +49,24 @@ int64_t sort_batch(int64_t segs, int64_t N) {
 int sort_layout(bh_ctx *c, int64_t segs, int64_t N, int64_t rounds, SortBufs *b) {
   b->stride = round_up(N, 64);
   b->nb = (int32_t)((N + bh::kSortTile - 1) / bh::kSortTile);
-  const int64_t arr = segs * b->stride * 4, hist = segs * 256 * b->nb * 4, tot = segs * 256 * 4,
+  const int64_t arr = segs * b->stride * 8, hist = segs * 256 * b->nb * 4, tot = segs * 256 * 4,
                 sub = round_up(segs * std::max<int64_t>(rounds, 1) * 8, 256);
   void *base = c->d_sort;
-  if (int rc = ensure_scratch(c, &base, &c->sort_cap, 4 * arr + hist + tot + sub)) {
+  if (int rc = ensure_scratch(c, &base, &c->sort_cap, 2 * arr + hist + tot + sub)) {
     c->d_sort = base;
     return rc;
   }
   c->d_sort = base;
   char *q = static_cast<char *>(base);
-  b->kA = reinterpret_cast<uint32_t *>(q);
-  b->kB = reinterpret_cast<uint32_t *>(q + arr);
-  b->vA = reinterpret_cast<int32_t *>(q + 2 * arr);
-  b->vB = reinterpret_cast<int32_t *>(q + 3 * arr);
-  b->hist = reinterpret_cast<uint32_t *>(q + 4 * arr);
-  b->tot = reinterpret_cast<uint32_t *>(q + 4 * arr + hist);
-  b->sub = reinterpret_cast<uint32_t *>(q + 4 * arr + hist + tot);
+  b->A = reinterpret_cast<uint2 *>(q);
+  b->B = reinterpret_cast<uint2 *>(q + arr);
+  b->hist = reinterpret_cast<uint32_t *>(q + 2 * arr);
+  b->tot = reinterpret_cast<uint32_t *>(q + 2 * arr + hist);
+  b->sub = reinterpret_cast<uint32_t *>(q + 2 * arr + hist + tot);
   return BH_OK;
 }
 
-// (kA, vA) of every segment sorted by key, stable, back into (kA, vA)
+// the elements in A of every segment sorted by key, stable, back into A
 int radix_sort(bh_ctx *c, const SortBufs &b, int64_t segs, int64_t N) {
   bh::SortParams p{};
   p.hist = b.hist;
@@ -79,10 +76,8 @@ int radix_sort(bh_ctx *c, const SortBufs &b, int64_t segs, int64_t N) {
   p.nb = b.nb;
   for (int pass = 0; pass < 4; ++pass) {
     const bool fwd = (pass & 1) == 0;
-    p.keys_in = fwd ? b.kA : b.kB;
-    p.vals_in = fwd ? b.vA : b.vB;
-    p.keys_out = fwd ? b.kB : b.kA;
-    p.vals_out = fwd ? b.vB : b.vA;
+    p.in = fwd ? b.A : b.B;
+    p.out = fwd ? b.B : b.A;
     p.shift = 8 * pass;
     const dim3 tiles((unsigned)b.nb, (unsigned)segs);
     hipLaunchKernelGGL(bh::sort_hist_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
@@ -98,7 +93,7 @@ int shuffle_rounds_for(int64_t n) {  // jax/_src/random.py `_shuffle`
 }
 
 // jax.random.permutation(key_e, N) for envs [env_first, env_first + segs) of E_total, key_e = split(env_key,
-// E_total + 1)[1 + e], side by side into b.vA (segment stride b.stride)
+// E_total + 1)[1 + e], side by side into the values of b.A (segment stride b.stride)
 int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int64_t env_first, int64_t segs, int64_t N,
                      int rounds, const SortBufs &b) {
   bh::ShuffleKeyParams kp{};
@@ -116,8 +111,7 @@ int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int6
   }
   bh::ShuffleGenParams gp{};
   gp.subkeys = b.sub;
-  gp.keys = b.kA;
-  gp.vals = b.vA;
+  gp.kv = b.A;
   gp.seg_stride = b.stride;
   gp.N = (int32_t)N;
   gp.rounds = rounds;
@@ -150,8 +144,7 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
       if (int rc = sort_layout(c, segs, n, 0, &b)) return rc;
       bh::ScoreKeyParams sp{};
       sp.scores = d_scores + r0 * n;
-      sp.keys = b.kA;
-      sp.vals = b.vA;
+      sp.kv = b.A;
       sp.seg_stride = b.stride;
       sp.N = (int32_t)n;
       hipLaunchKernelGGL(bh::score_keys_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
@@ -159,7 +152,7 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
       BH_HIP(hipGetLastError());
       if (int rc = radix_sort(c, b, segs, n)) return rc;
       hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)segs), dim3(256), 0,
-                         c->stream, b.vA, b.stride, (int32_t)k, d_idx_out + r0 * k);
+                         c->stream, b.A, b.stride, (int32_t)k, d_idx_out + r0 * k);
       BH_HIP(hipGetLastError());
       r0 += segs;
     }
@@ -335,7 +328,7 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
         if (int rc = sort_layout(c, segs, n_pairs, rounds, &b)) return rc;
         if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_pairs, rounds, b)) return rc;
         bh::PairActionParams q{};
-        q.perm = b.vA;
+        q.perm = b.A;
         q.best = static_cast<const int32_t *>(best) + e0 * k;
         q.actions = d_actions + e0 * n * 2;
         q.seg_stride = b.stride;
@@ -375,7 +368,7 @@ static int founders_device_impl(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, 
         if (int rc = sort_layout(c, segs, n_germplasm, rounds, &b)) return rc;
         if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_germplasm, rounds, b)) return rc;
         hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
-                           c->stream, b.vA, b.stride, (int32_t)n, d_out + e0 * n);
+                           c->stream, b.A, b.stride, (int32_t)n, d_out + e0 * n);
         BH_HIP(hipGetLastError());
         e0 += segs;
       }

@@ -12,8 +12,8 @@
 //     sort_scatter_kernel  every element to  base(value) + prefix(value, tile) + its rank among the tile's
 //                          elements of the same value, in index order
 // so equal words keep their order: the position is the tiebreak, as in the LDS kernels' (word << 32 | position).
-// Segments (envs) are sorted side by side: blockIdx.y is the segment.  HBM-bound: a pass reads 12 and writes
-// 8 bytes per element.
+// Segments (envs) are sorted side by side: blockIdx.y is the segment.  HBM-bound: a pass reads 16 and writes
+// 8 bytes per element (keys and values travel as one 8-byte word).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,14 +28,14 @@ constexpr int kSortItems = 16;                         // elements per lane
 constexpr int kSortTile = kSortThreads * kSortItems;   // 8192 elements per workgroup and pass
 constexpr int kSortWaveSpan = 64 * kSortItems;         // consecutive elements one wave ranks
 
+// an element: .x the 32-bit key, .y the value carried along -- one 8-byte word, so that the scatter of a pass is one
+// store per element (two 4-byte stores to two arrays ran at half the rate: profiles/r03_sort_pairs.txt)
 struct SortParams {
-  const uint32_t *keys_in;
-  const int32_t *vals_in;
-  uint32_t *keys_out;
-  int32_t *vals_out;
+  const uint2 *in;
+  uint2 *out;
   uint32_t *hist;       // (segs, 256, nb): counts, then exclusive prefixes over the tiles
   uint32_t *bin_total;  // (segs, 256)
-  int64_t seg_stride;   // elements from one segment to the next in keys / vals
+  int64_t seg_stride;   // elements from one segment to the next
   int32_t N, nb, shift;
 };
 
@@ -44,12 +44,12 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const SortParam
   const int tid = threadIdx.x, tile = blockIdx.x, seg = blockIdx.y;
   if (tid < 256) cnt[tid] = 0;
   __syncthreads();
-  const uint32_t *keys = p.keys_in + (int64_t)seg * p.seg_stride;
+  const uint2 *in = p.in + (int64_t)seg * p.seg_stride;
   const int base = tile * kSortTile;
 #pragma unroll 4
   for (int j = 0; j < kSortItems; ++j) {
     const int i = base + j * kSortThreads + tid;
-    if (i < p.N) atomicAdd(&cnt[(keys[i] >> p.shift) & 255u], 1u);
+    if (i < p.N) atomicAdd(&cnt[(in[i].x >> p.shift) & 255u], 1u);
   }
   __syncthreads();
   if (tid < 256) p.hist[((int64_t)seg * 256 + tid) * p.nb + tile] = cnt[tid];
@@ -120,25 +120,21 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortPa
   }
   __syncthreads();
 
-  const uint32_t *keys = p.keys_in + (int64_t)seg * p.seg_stride;
-  const int32_t *vals = p.vals_in + (int64_t)seg * p.seg_stride;
+  const uint2 *in = p.in + (int64_t)seg * p.seg_stride;
   const int wbase = tile * kSortTile + wv * kSortWaveSpan;
-  uint32_t k[kSortItems];
-  int32_t v[kSortItems];
+  uint2 e[kSortItems];
   unsigned lr[kSortItems];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const int i = wbase + j * 64 + lane;
-    const bool valid = i < p.N;
-    k[j] = valid ? keys[i] : 0u;
-    v[j] = valid ? vals[i] : 0;
+    e[j] = i < p.N ? in[i] : make_uint2(0u, 0u);
   }
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const int i = wbase + j * 64 + lane;
     const bool valid = i < p.N;
-    const unsigned d = (k[j] >> p.shift) & 255u;
+    const unsigned d = (e[j].x >> p.shift) & 255u;
     uint64_t peers = __ballot(valid);  // the lanes of this trip that carry the same digit value
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -165,16 +161,11 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const SortPa
     }
   }
   __syncthreads();
-  uint32_t *ko = p.keys_out + (int64_t)seg * p.seg_stride;
-  int32_t *vo = p.vals_out + (int64_t)seg * p.seg_stride;
+  uint2 *out = p.out + (int64_t)seg * p.seg_stride;
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const int i = wbase + j * 64 + lane;
-    if (i < p.N) {
-      const unsigned dst = cnt[wv][(k[j] >> p.shift) & 255u] + lr[j];
-      ko[dst] = k[j];
-      vo[dst] = v[j];
-    }
+    if (i < p.N) out[cnt[wv][(e[j].x >> p.shift) & 255u] + lr[j]] = e[j];
   }
 }
 
@@ -202,8 +193,7 @@ __global__ void shuffle_subkeys_kernel(const ShuffleKeyParams p) {
 
 struct ShuffleGenParams {
   const uint32_t *subkeys;  // (segs, rounds, 2)
-  uint32_t *keys;           // (segs, seg_stride): random_bits(sub, N)
-  int32_t *vals;            // (segs, seg_stride): set to 0..N-1 when `init`
+  uint2 *kv;                // (segs, seg_stride): .x = random_bits(sub, N), .y = 0..N-1 when `init`, else kept
   int64_t seg_stride;
   int32_t N, rounds, round, layout, init;
 };
@@ -213,24 +203,23 @@ __global__ __launch_bounds__(256) void shuffle_gen_kernel(const ShuffleGenParams
   const int seg = blockIdx.y;
   const uint32_t s0 = p.subkeys[((int64_t)seg * p.rounds + p.round) * 2],
                  s1 = p.subkeys[((int64_t)seg * p.rounds + p.round) * 2 + 1];
-  uint32_t *keys = p.keys + (int64_t)seg * p.seg_stride;
-  int32_t *vals = p.vals + (int64_t)seg * p.seg_stride;
+  uint2 *kv = p.kv + (int64_t)seg * p.seg_stride;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (p.layout == LAYOUT_PARTITIONABLE) {
     if (i < p.N) {
-      keys[i] = bits_word_partitionable(s0, s1, (uint32_t)i);
-      if (p.init) vals[i] = i;
+      kv[i].x = bits_word_partitionable(s0, s1, (uint32_t)i);
+      if (p.init) kv[i].y = (uint32_t)i;
     }
   } else {
     const int h = (p.N + 1) >> 1;
     if (i < h) {
       const bool second = i + h < p.N;  // odd N: the last pair is padded with a 0 counter
       const u32x2 o = threefry2x32(s0, s1, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
-      keys[i] = o.x;
-      if (p.init) vals[i] = i;
+      kv[i].x = o.x;
+      if (p.init) kv[i].y = (uint32_t)i;
       if (second) {
-        keys[i + h] = o.y;
-        if (p.init) vals[i + h] = i + h;
+        kv[i + h].x = o.y;
+        if (p.init) kv[i + h].y = (uint32_t)(i + h);
       }
     }
   }
@@ -239,8 +228,7 @@ __global__ __launch_bounds__(256) void shuffle_gen_kernel(const ShuffleGenParams
 // keys for jax.lax.top_k as a sort: ascending ~orderable(score) = descending score, ties to the lower index
 struct ScoreKeyParams {
   const float *scores;  // (segs, N)
-  uint32_t *keys;
-  int32_t *vals;
+  uint2 *kv;
   int64_t seg_stride;
   int32_t N;
 };
@@ -249,21 +237,19 @@ __global__ __launch_bounds__(256) void score_keys_kernel(const ScoreKeyParams p)
   const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.N) return;
   const uint32_t u = __float_as_uint(p.scores[(int64_t)seg * p.N + i]);
-  p.keys[(int64_t)seg * p.seg_stride + i] = ~(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u));
-  p.vals[(int64_t)seg * p.seg_stride + i] = i;
+  p.kv[(int64_t)seg * p.seg_stride + i] = make_uint2(~(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)), (uint32_t)i);
 }
 
-// out[s, 0:take] = vals[s, 0:take]
-__global__ __launch_bounds__(256) void take_front_kernel(const int32_t *vals, int64_t seg_stride, int32_t take,
-                                                         int32_t *out) {
+// out[s, 0:take] = the values of the first `take` elements of segment s
+__global__ __launch_bounds__(256) void take_front_kernel(const uint2 *kv, int64_t seg_stride, int32_t take, int32_t *out) {
   const int seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  if (i < take) out[(int64_t)seg * take + i] = vals[(int64_t)seg * seg_stride + i];
+  if (i < take) out[(int64_t)seg * take + i] = (int32_t)kv[(int64_t)seg * seg_stride + i].y;
 }
 
 // `SelectionScores._convert_actions`' tail (vec_wrappers.py:66-79) from a shuffled list of pair ranks:
 // slot s of env e takes pair perm[s / n_offspring]; rank t -> (i, j), i < j, row-major upper triangle of k x k.
 struct PairActionParams {
-  const int32_t *perm;  // (segs, seg_stride) shuffled pair ranks (the first n_crosses are read)
+  const uint2 *perm;    // (segs, seg_stride) shuffled elements, .y = pair rank (the first n_crosses are read)
   const int32_t *best;  // (segs, k) top-k indices, best first
   int32_t *actions;     // (segs, n, 2)
   int64_t seg_stride;
@@ -273,7 +259,7 @@ struct PairActionParams {
 __global__ __launch_bounds__(256) void pair_actions_kernel(const PairActionParams p) {
   const int seg = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
   if (s >= p.n) return;
-  const int64_t t = p.perm[(int64_t)seg * p.seg_stride + s / p.n_offspring], k = p.k;
+  const int64_t t = p.perm[(int64_t)seg * p.seg_stride + s / p.n_offspring].y, k = p.k;
   // rows before row i hold i (2k - i - 1) / 2 pairs
   const double b = 2.0 * (double)k - 1.0;
   int64_t i = (int64_t)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
