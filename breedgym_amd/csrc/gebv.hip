@@ -97,7 +97,7 @@ constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
     p.mc_per_slice = (int32_t)per_slice;
     p.row_groups = (int32_t)row_groups;
     p.slices = (int32_t)slices;
-    const dim3 grid((unsigned)(8 * row_groups * ((slices + 7) / 8)));
+    const dim3 grid(bh::slice_grid(row_groups, slices));
     if (nt == 1)
       hipLaunchKernelGGL((bh::gebv_bits_kernel<1, F>), grid, dim3(256), 0, c->stream, p);
     else
@@ -150,7 +150,7 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
     p.mc_per_slice = (int32_t)per_slice;
     p.row_groups = (int32_t)row_groups;
     p.slices = (int32_t)slices;
-    const dim3 grid((unsigned)(8 * row_groups * ((slices + 7) / 8)));
+    const dim3 grid(bh::slice_grid(row_groups, slices));
     if (nt == 1)
       hipLaunchKernelGGL((bh::gebv_bytes_kernel<1>), grid, dim3(256), 0, c->stream, p);
     else

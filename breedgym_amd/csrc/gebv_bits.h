@@ -51,10 +51,20 @@ struct GebvBitsParams {
 // markers, more than one L2 holds) come into that L2 once and are met there by every row group, instead of every
 // XCD pulling the whole pack through the fabric once per row group.  Placement only changes speed.
 __device__ __forceinline__ bool slice_of_block(int row_groups, int slices, int &rg, int &slice) {
-  const int b = (int)blockIdx.x, i = b >> 3;
+  const int b = (int)blockIdx.x;
+  if (slices < 8) {  // fewer slices than XCDs (many rows, short K): nothing to place, row groups over all XCDs
+    rg = b % row_groups;
+    slice = b / row_groups;
+    return true;
+  }
+  const int i = b >> 3;
   rg = i % row_groups;
   slice = (i / row_groups) * 8 + (b & 7);
   return slice < slices;
+}
+// the grid that goes with it
+inline unsigned slice_grid(int64_t row_groups, int64_t slices) {
+  return (unsigned)(slices < 8 ? row_groups * slices : 8 * row_groups * ((slices + 7) / 8));
 }
 
 // 16 markers (one dword of a bit-plane row: bits 2k, 2k+1 = the alleles of marker k) -> 16 dosage bytes.

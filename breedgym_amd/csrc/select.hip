@@ -67,24 +67,29 @@ int sort_layout(bh_ctx *c, int64_t segs, int64_t N, int64_t rounds, SortBufs *b)
 }
 
 // the elements in A of every segment sorted by key, stable, back into A
-int radix_sort(bh_ctx *c, const SortBufs &b, int64_t segs, int64_t N) {
+// one stable pass on 8 bits of the key: in -> out (tiles of `nb` per segment; hist / tot as in `b`)
+int radix_pass(bh_ctx *c, const SortBufs &b, const uint2 *in, uint2 *out, int64_t segs, int64_t N, int shift) {
   bh::SortParams p{};
+  p.in = in;
+  p.out = out;
   p.hist = b.hist;
   p.bin_total = b.tot;
   p.seg_stride = b.stride;
   p.N = (int32_t)N;
-  p.nb = b.nb;
-  for (int pass = 0; pass < 4; ++pass) {
-    const bool fwd = (pass & 1) == 0;
-    p.in = fwd ? b.A : b.B;
-    p.out = fwd ? b.B : b.A;
-    p.shift = 8 * pass;
-    const dim3 tiles((unsigned)b.nb, (unsigned)segs);
-    hipLaunchKernelGGL(bh::sort_hist_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
-    hipLaunchKernelGGL(bh::sort_scan_kernel, dim3(256, (unsigned)segs), dim3(256), 0, c->stream, p);
-    hipLaunchKernelGGL(bh::sort_scatter_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
-    BH_HIP(hipGetLastError());
-  }
+  p.nb = (int32_t)((N + bh::kSortTile - 1) / bh::kSortTile);
+  p.shift = shift;
+  const dim3 tiles((unsigned)p.nb, (unsigned)segs);
+  hipLaunchKernelGGL(bh::sort_hist_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
+  hipLaunchKernelGGL(bh::sort_scan_kernel, dim3(256, (unsigned)segs), dim3(256), 0, c->stream, p);
+  hipLaunchKernelGGL(bh::sort_scatter_kernel, tiles, dim3(bh::kSortThreads), 0, c->stream, p);
+  BH_HIP(hipGetLastError());
+  return BH_OK;
+}
+
+// the first N elements of every segment of `x` sorted by key, stable, back into `x` (`y`: the other array of `b`)
+int radix_sort(bh_ctx *c, const SortBufs &b, uint2 *x, uint2 *y, int64_t segs, int64_t N) {
+  for (int pass = 0; pass < 4; ++pass)
+    if (int rc = radix_pass(c, b, (pass & 1) ? y : x, (pass & 1) ? x : y, segs, N, 8 * pass)) return rc;
   return BH_OK;
 }
 
@@ -92,10 +97,19 @@ int shuffle_rounds_for(int64_t n) {  // jax/_src/random.py `_shuffle`
   return (int)std::ceil(3.0 * std::log((double)std::max<int64_t>(1, n)) / std::log(4294967295.0));
 }
 
-// jax.random.permutation(key_e, N) for envs [env_first, env_first + segs) of E_total, key_e = split(env_key,
-// E_total + 1)[1 + e], side by side into the values of b.A (segment stride b.stride)
+// jax.random.permutation(key_e, N)[:take] for envs [env_first, env_first + segs) of E_total, key_e = split(env_key,
+// E_total + 1)[1 + e], side by side as the values of the first `take` elements of every segment of *result (b.A or
+// b.B, segment stride b.stride).
+//
+// Only the front of the last round's order is wanted, and a long list (k(k-1)/2 = 21.5 M pair ranks for 8192 crosses
+// at BASELINE configs[3]) is not worth sorting whole for it: the last round runs ONE pass on the top byte of its keys
+// (stable, like the others), which leaves the elements grouped by that byte; the host reads how many fall into the
+// first groups (a 1 KB copy per segment: the one synchronisation of the call), and only that front -- the groups that
+// hold the `take` smallest keys, ~N/256 elements -- is sorted completely.  Three of the round's four passes shrink
+// to almost nothing.
 int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int64_t env_first, int64_t segs, int64_t N,
-                     int rounds, const SortBufs &b) {
+                     int rounds, int64_t take, const SortBufs &b, const uint2 **result) {
+  *result = b.A;
   bh::ShuffleKeyParams kp{};
   kp.subkeys = b.sub;
   kp.key0 = env_key[0];
@@ -118,13 +132,29 @@ int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int6
   gp.layout = c->layout;
   const int64_t per_seg = c->layout == bh::LAYOUT_PARTITIONABLE ? N : (N + 1) / 2;
   const dim3 grid((unsigned)((per_seg + 255) / 256), (unsigned)segs);
+  const bool front_only = N >= ((int64_t)1 << 20) && take * 64 <= N;
   for (int rd = 0; rd < std::max(rounds, 1); ++rd) {  // N = 1: no round, the identity
     gp.round = rd;
     gp.init = rd == 0;
     hipLaunchKernelGGL(bh::shuffle_gen_kernel, grid, dim3(256), 0, c->stream, gp);
     BH_HIP(hipGetLastError());
     if (rounds == 0) break;
-    if (int rc = radix_sort(c, b, segs, N)) return rc;
+    if (rd + 1 < rounds || !front_only) {
+      if (int rc = radix_sort(c, b, b.A, b.B, segs, N)) return rc;
+      continue;
+    }
+    if (int rc = radix_pass(c, b, b.A, b.B, segs, N, 24)) return rc;  // grouped by the top byte, in b.B
+    std::vector<uint32_t> tot((size_t)segs * 256);
+    BH_HIP(hipMemcpyAsync(tot.data(), b.tot, tot.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    BH_HIP(hipStreamSynchronize(c->stream));
+    int64_t front = 0;  // the longest front any segment needs
+    for (int64_t sg = 0; sg < segs; ++sg) {
+      int64_t run = 0;
+      for (int d = 0; d < 256 && run < take; ++d) run += tot[(size_t)sg * 256 + d];
+      front = std::max(front, run);
+    }
+    if (int rc = radix_sort(c, b, b.B, b.A, segs, front)) return rc;
+    *result = b.B;
   }
   return BH_OK;
 }
@@ -150,7 +180,7 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
       hipLaunchKernelGGL(bh::score_keys_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
                          c->stream, sp);
       BH_HIP(hipGetLastError());
-      if (int rc = radix_sort(c, b, segs, n)) return rc;
+      if (int rc = radix_sort(c, b, b.A, b.B, segs, n)) return rc;
       hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)segs), dim3(256), 0,
                          c->stream, b.A, b.stride, (int32_t)k, d_idx_out + r0 * k);
       BH_HIP(hipGetLastError());
@@ -326,9 +356,10 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
         const int64_t segs = std::min(sort_batch(n_envs, n_pairs), n_envs - e0);
         SortBufs b{};
         if (int rc = sort_layout(c, segs, n_pairs, rounds, &b)) return rc;
-        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_pairs, rounds, b)) return rc;
+        const uint2 *perm = nullptr;
+        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_pairs, rounds, n_crosses, b, &perm)) return rc;
         bh::PairActionParams q{};
-        q.perm = b.A;
+        q.perm = perm;
         q.best = static_cast<const int32_t *>(best) + e0 * k;
         q.actions = d_actions + e0 * n * 2;
         q.seg_stride = b.stride;
@@ -366,9 +397,10 @@ static int founders_device_impl(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, 
         const int64_t segs = std::min(sort_batch(n_envs, n_germplasm), n_envs - e0);
         SortBufs b{};
         if (int rc = sort_layout(c, segs, n_germplasm, rounds, &b)) return rc;
-        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_germplasm, rounds, b)) return rc;
+        const uint2 *perm = nullptr;
+        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_germplasm, rounds, n, b, &perm)) return rc;
         hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
-                           c->stream, b.A, b.stride, (int32_t)n, d_out + e0 * n);
+                           c->stream, perm, b.stride, (int32_t)n, d_out + e0 * n);
         BH_HIP(hipGetLastError());
         e0 += segs;
       }

@@ -26,7 +26,8 @@ def tiny_engine(layout):
 
 
 @pytest.mark.parametrize("N,n,E", [(8193, 50, 2), (10000, 10000, 3), (16385, 4096, 2), (65536, 8192, 2),
-                                     (65536, 65536, 1), (100001, 1000, 5), (1 << 20, 4096, 1)])
+                                     (65536, 65536, 1), (100001, 1000, 5), (1 << 20, 4096, 1),
+                                     ((1 << 20) + 3, 1000, 3)])  # the last two: only the front of the last round is sorted
 def test_founder_draw_large_germplasm(N, n, E, layout):
     eng = tiny_engine(layout)
     key0 = co.key_from_seed(1234)
