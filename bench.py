@@ -108,10 +108,21 @@ def cpu_baseline(gm, geno, rng_mode, seconds_hint=12.0):
     return res
 
 
+SETTLE_S = 0.1  # untimed steps before the warm-up: the GPU's clocks take tens of ms under load to settle (a 200-step
+                # sample right after start-up reads 27 us per step, the same loop 15 ms later 25)
+
+
 def time_steps(env, actions, steps, warmup, barrier):
     """-> (seconds for `steps` steps incl. the final sync, seconds the host needed to issue them)."""
     import torch
 
+    t_end = time.perf_counter() + SETTLE_S
+    i = 0
+    while time.perf_counter() < t_end:
+        env.step(actions[i % len(actions)])
+        i += 1
+        if i % 64 == 0:
+            torch.cuda.synchronize()  # keep the queue short: the wall clock, not the backlog, ends the settling
     for i in range(warmup):
         env.step(actions[i % len(actions)])
     barrier()
@@ -657,6 +668,7 @@ def main():
                 step_frac_of_hbm_peak=nbytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBPS,
             ),
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
+            "settle_s": SETTLE_S,  # untimed steps for that long before the W warm-up steps (clock settling)
         }
         if ti is not None:
             line["independent_rng"] = {
