@@ -23,6 +23,7 @@ namespace bh {
 constexpr int kLongRowPrio = 2;  // priority of the row waves of the long-row stream
 constexpr int kLongRowVectors = 4;   // vectors per lane and trip in the long-row stream
 constexpr int kShortRowVectors = 2;  // ... and in the stream with GEBV
+constexpr int kLongAhead = 1, kShortAhead = 1;  // trips the stream requests ahead: without / with GEBV
 
 struct PackedParams {
   const uint16_t *src;  // cross: (E, n_pool, nvp) packed pool; gather: (n_pool, nvp)
@@ -291,8 +292,6 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         }
       }
     };
-constexpr int kLongAhead = 1;  // trips the stream requests ahead: without / with GEBV
-constexpr int kShortAhead = 1;
     constexpr int AHEAD = TT == 0 ? kLongAhead : kShortAhead;
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
