@@ -389,6 +389,38 @@ class VecBreedGym(_VectorEnvBase):
     def set_attr(self, name, values):
         return setattr(self, name, values)
 
+    # ---- checkpoint / resume ---------------------------------------------------------------------
+    # The reference has none; its env state is `populations`, `step_idx`, `random_key` and the simulator's key
+    # (vec_env.py:70-73).  Restoring those four continues an episode bit for bit.
+    def get_state(self) -> dict:
+        """Everything a later ``set_state`` needs to continue exactly here, as host arrays (populations as bit planes:
+        1 bit per allele)."""
+        if self._n is None:
+            raise RuntimeError("call reset() before get_state()")
+        eng = self.simulator.engine
+        packed = self._prows if self._prows is not None else eng.pack(self._brows)
+        return {
+            "populations_packed": packed.cpu().numpy().copy(), "individual_per_gen": int(self._n),
+            "num_envs": self.num_envs, "n_markers": int(self.simulator.n_markers), "step_idx": int(self.step_idx),
+            "random_key": np.array(self.random_key, np.uint32).copy(),
+            "simulator_key": np.array(self.simulator.random_key, np.uint32).copy(),
+        }
+
+    def set_state(self, state: dict) -> None:
+        eng = self.simulator.engine
+        if state["num_envs"] != self.num_envs or state["n_markers"] != self.simulator.n_markers:
+            raise ValueError("the state belongs to an env of another shape")
+        n = int(state["individual_per_gen"])
+        packed = torch.from_numpy(np.ascontiguousarray(state["populations_packed"])).to(eng.device)
+        if packed.shape != (self.num_envs * n, eng.packed_pitch):
+            raise ValueError("populations_packed has the wrong shape")
+        rows = eng.unpack(packed) if (self.storage == "bytes" or self.observations == "eager") else None
+        self._adopt(rows, n, packed if self.storage == "bits" else None)
+        self.step_idx = int(state["step_idx"])
+        self.random_key = np.array(state["random_key"], np.uint32).copy()
+        self.simulator.random_key = np.array(state["simulator_key"], np.uint32).copy()
+        self._founders_ahead, self._rew_primed = None, None
+
     def close(self, **kwargs):
         if self._ring is not None:
             self._ring.close()

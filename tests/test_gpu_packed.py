@@ -331,3 +331,30 @@ def test_block_pool_equals_fresh_blocks(observations, rng):
     assert len({k.data_ptr() if hasattr(k, "data_ptr") else id(k) for k in keep}) == 5 and len(tiny._ring.slots) == 2
     with pytest.raises(ValueError):
         VecBreedGym(block_pool=1, **kw)
+
+
+@pytest.mark.parametrize("storage,observations", [("bits", "eager"), ("bits", "lazy"), ("bytes", "eager")])
+def test_checkpoint_resume_on_device(storage, observations, rng):
+    """get_state / set_state (the env state of vec_env.py:70-73): an episode continued in a fresh env on the device is
+    the episode continued in the old one, through the horizon and its autoreset"""
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    E, n, M = 3, 33, 1500
+    gm = synthetic_genetic_map(M, n_chr=3, seed=2)
+    geno = synthetic_genotypes(60, M, seed=3)
+    kw = dict(num_envs=E, initial_population=geno, individual_per_gen=n, genetic_map=gm, num_generations=5,
+              reward_shaping=True, storage=storage, observations=observations)
+    a, b = VecBreedGym(**kw), VecBreedGym(**kw)
+    a.reset(seed=5)
+    for _ in range(2):
+        a.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))
+    b.reset(seed=99)
+    b.set_state(a.get_state())
+    for _ in range(5):
+        act = rng.integers(0, n, (E, n, 2), dtype=np.int32)
+        pa, ra, _, ta, ia = a.step(act)
+        pb, rb, _, tb, ib = b.step(act)
+        assert np.array_equal(np.asarray(pa), np.asarray(pb)) and np.array_equal(ra, rb) and np.array_equal(ta, tb)
+        assert np.array_equal(np.asarray(ia["GEBV"]), np.asarray(ib["GEBV"]))
+    assert np.array_equal(a.random_key, b.random_key) and np.array_equal(a.simulator.random_key, b.simulator.random_key)

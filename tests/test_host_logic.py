@@ -358,6 +358,28 @@ def test_wheat_breed_gym(data):
         WheatBreedGym(env, n_lines=2, plant_per_line=5, k_per_line=2)  # 4 plants < individual_per_gen
 
 
+@pytest.mark.parametrize("storage", ["bits", "bytes"])
+def test_checkpoint_resume(data, storage):
+    """get_state / set_state: an episode continued in a fresh env is the episode continued in the old one"""
+    kw = dict(num_envs=3, individual_per_gen=9, num_generations=6, reward_shaping=True, storage=storage)
+    a, b = make_vec(data, **kw), make_vec(data, **kw)
+    a.reset(seed=5)
+    arng = np.random.default_rng(0)
+    for _ in range(2):
+        a.step(arng.integers(0, 9, (3, 9, 2)))
+    state = a.get_state()
+    b.reset(seed=99)  # anything
+    b.set_state(state)
+    assert np.array_equal(np.asarray(a.populations), np.asarray(b.populations))
+    for _ in range(6):  # through the horizon and the autoreset
+        act = arng.integers(0, 9, (3, 9, 2))
+        pa, ra, _, ta, ia = a.step(act)
+        pb, rb, _, tb, ib = b.step(act)
+        assert np.array_equal(np.asarray(pa), np.asarray(pb)) and np.array_equal(ra, rb) and np.array_equal(ta, tb)
+        assert np.array_equal(np.asarray(ia["GEBV"]), np.asarray(ib["GEBV"]))
+    assert np.array_equal(a.random_key, b.random_key) and np.array_equal(a.simulator.random_key, b.simulator.random_key)
+
+
 @pytest.mark.parametrize("observations", ["eager", "lazy"])
 def test_wheat_breed_gym_bit_planes_equal_byte_rows(data, observations):
     """The wheat generation on bit planes (storage="bits", the default) makes the plants the byte-layout route makes."""
