@@ -61,10 +61,11 @@ int bh_device_count(int *count) {
 }
 
 int64_t bh_max_markers(void) {
-  // what the 32-bit offsets inside a row and the tested shapes cover (the reference's largest: 1,406,757 markers,
-  // scripts/time_cross.py:14).  Up to 2^18 markers a cross's site words stay in LDS; beyond, they go through
-  // memory (mask_stream.h)
-  return (int64_t)1 << 22;
+  // 2^21: up to there a lane's int32 digit sums of the in-stream GEBV cannot wrap whatever the effects are (M / 64
+  // markers per lane x dosage 2 x |digit| <= 2^15), and the tested shapes lie inside (the reference's largest:
+  // 1,406,757 markers, scripts/time_cross.py:14).  Up to 2^18 markers a cross's site words stay in LDS; beyond, they
+  // go through memory (mask_stream.h)
+  return (int64_t)1 << 21;
 }
 
 int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *recomb_vec,

@@ -259,7 +259,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     // digits (as gebv_mfma.h cuts them into six base-256 ones), the dosages of a marker pair are the
     // two int16 halves of (w + (w >> 8)) & 0x00FF00FF, and a v_dot2_i32_i16 per pair and digit replaces
     // eight conversions and eight f64 FMAs per vector.  |digit| <= 2^15 and dosage <= 2, so a lane's
-    // int32 sums stay below 2^31 for rows of up to 2^21 markers (bh_max_markers() is 2^18).
+    // int32 sums stay within int32 for rows of up to 2^21 markers = bh_max_markers().
     int acc[R][NT][3];
 #pragma unroll
     for (int r = 0; r < R; ++r)

@@ -85,7 +85,7 @@ int bh_sync(bh_ctx *ctx);
 int64_t bh_row_pitch(const bh_ctx *ctx);
 int64_t bh_n_markers(const bh_ctx *ctx);
 int64_t bh_n_traits(const bh_ctx *ctx);
-/* largest marker count a context takes (2^22; the reference's largest shape, scripts/time_cross.py:14, has
+/* largest marker count a context takes (2^21; the reference's largest shape, scripts/time_cross.py:14, has
  * 1,406,757 markers) */
 int64_t bh_max_markers(void);
 

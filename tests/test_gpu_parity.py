@@ -313,7 +313,7 @@ def test_recombination_probability_edges(M, rng):
                                      (1626, 64, 2), (5000, 4999, 2), (8192, 100, 3), (8193, 50, 2)])
 def test_founder_draw_on_device(N, n, E):
     """the reset founder draw (jax.random.choice without replacement per env) == oracle, incl. the
-    two-round shuffle (N > 1625) and the host fallback (N > 8192)"""
+    two-round shuffle (N > 1625) and the radix-sort route (N > 8192)"""
     eng = make_engine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32))
     for seed in (7, 12345):
         got, key = eng.founders(co.key_from_seed(seed), E, N, n)
