@@ -7,6 +7,8 @@
 //                         horizon launch);  above: JAX's shuffle rounds as radix sorts in HBM, envs side by side
 //   bh_selection_actions  n <= 8192 and k(k-1)/2 <= 8192: one workgroup per env in LDS (selection_actions_kernel);
 //                         above: bh_topk's routes for the k best, radix-sort shuffle of the pair ranks, un-ranking
+//   bh_pair_actions       bh_topk's routes for the n best of n x n pair scores, then one workgroup per env
+//                         (softmax, offspring counts, repeat: pair_score_actions_kernel)
 #include "ctx.h"
 #include "select_kernels.h"
 #include "sort_kernels.h"
@@ -375,6 +377,35 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
   }
   env_key[0] = nk.x;
   env_key[1] = nk.y;
+  return BH_OK;
+}
+
+int bh_pair_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n, int32_t *d_actions) {
+  if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
+  if (n_envs < 0 || n <= 0) return fail(BH_ERR_BAD_ARG, "bh_pair_actions: bad sizes");
+  if (n > 16384 || n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_pair_actions: n <= 16384 and n_envs <= 65535");
+  if (n_envs == 0) return BH_OK;
+  if (!d_scores || !d_actions) return fail(BH_ERR_BAD_ARG, "bh_pair_actions: null device pointer");
+  void *best = c->d_best;
+  const int rc0 = ensure_scratch(c, &best, &c->best_cap, n_envs * n * 4);
+  c->d_best = best;
+  if (rc0) return rc0;
+  if (int rc = topk_impl(c, d_scores, n_envs, n * n, n, static_cast<int32_t *>(best))) return rc;
+  bh::PairScoreParams p{};
+  p.scores = d_scores;
+  p.best = static_cast<const int32_t *>(best);
+  p.actions = d_actions;
+  p.n = (int32_t)n;
+  const size_t lds = (size_t)n * 8;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::pair_score_actions_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(pair scores LDS): %s", hipGetErrorString(e));
+  }
+  const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, (n + 63) / 64 * 64));
+  hipLaunchKernelGGL(bh::pair_score_actions_kernel, dim3((unsigned)n_envs), dim3(threads), lds, c->stream, p);
+  BH_HIP(hipGetLastError());
   return BH_OK;
 }
 

@@ -266,4 +266,78 @@ __global__ __launch_bounds__(1024) void selection_actions_kernel(const Selection
   }
 }
 
+// `PairScores._convert_actions` (breedgym/vector/vec_wrappers.py:100-112) behind the top-n of the n x n pair scores,
+// one workgroup per env:
+//     vals  = scores[best]                         the n best pair scores, best first
+//     sm    = softmax(vals)                        f32; the one order-dependent step -- the sum -- in f64, rounded once
+//     count = ceil(sm * n)                         offspring per pair
+//     out   = repeat(pairs[best], count)[:n]       slot s takes the first pair whose cumulative count exceeds s
+// (the reference's jnp.repeat(..., total_repeat_length=n)); pair = (best // n, best % n).
+struct PairScoreParams {
+  const float *scores;  // (E, n * n)
+  const int32_t *best;  // (E, n) flat indices of the n best, best first (bh_topk)
+  int32_t *actions;     // (E, n, 2)
+  int32_t n;
+};
+
+__global__ __launch_bounds__(1024) void pair_score_actions_kernel(const PairScoreParams p) {
+  extern __shared__ __align__(16) float ps_lds[];  // n f32 (exp), n int32 (cumulative counts)
+  __shared__ double part[16];
+  __shared__ int carry;
+  float *ex = ps_lds;
+  int32_t *ends = reinterpret_cast<int32_t *>(ps_lds + p.n);
+  const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, n = p.n;
+  const float *sc = p.scores + (int64_t)e * n * n;
+  const int32_t *best = p.best + (int64_t)e * n;
+  const float vmax = sc[best[0]];  // best first: the largest score
+  double local = 0.0;
+  for (int i = tid; i < n; i += nt) {
+    const float x = expf(sc[best[i]] - vmax);
+    ex[i] = x;
+    local += (double)x;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+  if (lane == 0) part[wv] = local;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  double total = 0.0;
+  for (int w = 0; w < (nt >> 6); ++w) total += part[w];
+  const float denom = (float)total;
+  // inclusive cumulative counts, a block of `nt` pairs at a time
+  for (int base = 0; base < n; base += nt) {
+    const int i = base + tid;
+    const int c = i < n ? (int)ceilf(ex[i] / denom * (float)n) : 0;
+    int v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(v, off);
+      if (lane >= off) v += t;
+    }
+    __syncthreads();  // (part is free again; carry of the previous block is final)
+    int *wsum = reinterpret_cast<int *>(part);
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    if (i < n) ends[i] = before + v;
+    __syncthreads();
+    if (tid == nt - 1) carry = before + v;
+  }
+  __syncthreads();
+  for (int s = tid; s < n; s += nt) {  // first pair whose cumulative count exceeds s
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ends[mid] > s)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    const int b = best[lo];
+    p.actions[((int64_t)e * n + s) * 2] = b / n;
+    p.actions[((int64_t)e * n + s) * 2 + 1] = b % n;
+  }
+}
+
 }  // namespace bh

@@ -529,6 +529,15 @@ class HipEngine(EngineBase):
         )
         return out, key
 
+    def pair_actions(self, scores, n: int) -> torch.Tensor:
+        """``PairScores._convert_actions`` for every env (bh_pair_actions): (E, n, n) pair scores -> (E, n, 2) int32."""
+        s = scores.as_subclass(torch.Tensor) if isinstance(scores, torch.Tensor) else torch.as_tensor(np.asarray(scores))
+        s = s.to(device=self.device, dtype=torch.float32).contiguous()
+        E = s.numel() // (n * n)
+        out = torch.empty((E, n, 2), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.bh_pair_actions(self._h, s.data_ptr(), E, int(n), out.data_ptr()))
+        return out
+
     def set_threefry_layout(self, layout) -> None:
         """"original" (jax_threefry_partitionable off: what the reference's seeded tests were recorded under) or
         "partitionable" (the default of jax >= 0.5): which JAX bit stream the device paths reproduce."""

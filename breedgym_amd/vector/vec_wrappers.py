@@ -105,6 +105,9 @@ class PairScores(VectorWrapper):
     def _convert_actions(self, actions):
         eng = self.simulator.engine
         n = self.n_crosses
+        if hasattr(eng, "pair_actions") and n <= 16384:  # one fused kernel behind the top-k (bh_pair_actions)
+            return eng.pair_actions(_as_device_f32(actions, eng), n)
+        # the same in tensor operations (engines without the kernel: the CPU test double)
         s = _as_device_f32(actions, eng).reshape(self.num_envs, n * n)
         best = eng.topk(s, n).to(torch.int64)  # (E, n) flat indices, best first
         vals = torch.gather(s, 1, best)

@@ -173,6 +173,12 @@ int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64
 int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
                          int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
 
+/* `PairScores._convert_actions` (vec_wrappers.py:100-112) for all envs: the n best of every env's n x n pair scores
+ * (jax.lax.top_k on the flattened matrix), offspring per pair = ceil(softmax(their scores) * n), pairs repeated that
+ * often and cut at n.  d_scores (E, n, n) f32 -> d_actions (E, n, 2) int32, pair = (flat index // n, flat index % n).
+ * The softmax is taken in f32 with its sum in f64, rounded once.  n <= 16384. */
+int bh_pair_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int32_t *d_actions);
+
 /* ---- bit-plane storage behind the byte-layout API ------------
  * The observation format of the reference stays what it is -- (rows, M, 2) one byte per allele
  * (vec_env.py:57-62) -- but a population a VecBreedGym keeps between steps can live packed, 1 bit

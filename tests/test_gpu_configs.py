@@ -716,3 +716,17 @@ def test_byte_row_gebv_in_one_pass(rows, M, T, rng):
     geno[0], geno[-1] = 1, 0  # the largest and the smallest sums
     got = eng.gebv(eng.upload_population(geno)).cpu().numpy()
     assert gebv_close(got, co.gebv(geno, eff, want64=True)[1])
+
+
+@pytest.mark.parametrize("E,n", [(1, 1), (3, 7), (4, 200), (2, 1000), (1, 1500)])
+def test_pair_actions_kernel(E, n, rng):
+    """bh_pair_actions (PairScores._convert_actions in one kernel behind the top-k) against the NumPy restatement of
+    vec_wrappers.py:100-112, incl. rows longer than one workgroup sorts (n * n > 16384) and exact score ties"""
+    from breedgym_amd import HipEngine
+
+    eng = HipEngine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32))
+    scores = rng.standard_normal((E, n, n)).astype(np.float32)
+    if n > 2:
+        scores[:, 1, 2] = scores[:, 0, 1] = scores.max() + 1.0  # two pairs tie for the best score
+    got = eng.pair_actions(torch.from_numpy(scores), n).cpu().numpy()
+    assert np.array_equal(got, _pair_actions_restated(scores, n))
