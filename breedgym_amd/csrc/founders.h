@@ -10,6 +10,37 @@
 
 namespace bh {
 
+// Ascending bitonic sort of P (a power of two) 64-bit keys in LDS by the whole workgroup.  Pair j of a stage touches
+// elements of ONE aligned block of 2 * stride keys, and the 64 pairs a wave takes in one turn are consecutive: while
+// stride <= 64 a wave stays inside its own aligned block of 128 keys, which nobody else touches in that stage -- and a
+// wave's LDS operations are served in order.  So a workgroup barrier is needed only around the stages that reach
+// further (15 of the 78 stages of a 4096-key sort); the others are separated by a wave-level fence.
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, int P) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int j = tid; j < (P >> 1); j += nt) {
+        const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      const int next = stride > 1 ? stride >> 1 : size;  // the stride of the stage that follows
+      if (stride > 64 || next > 64) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---- founder draw of VecBreedGym.reset on the device ---------------------------------------
 // env e: key_e = split(env_key, E+1)[1+e]; permutation(key_e, N)[:n] by jax's `_shuffle`:
 // `rounds` times { key, sub = split(key); stable-sort the current order by random_bits(sub, N) }.
@@ -46,20 +77,7 @@ __device__ __forceinline__ void founders_role(const FoundersParams &p, const int
     }
     for (int i = p.N + tid; i < p.P; i += nt) fk[i] = ~0ull;
     __syncthreads();
-    for (int size = 2; size <= p.P; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int j = tid; j < (p.P >> 1); j += nt) {
-          const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1)), hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          const uint64_t a = fk[lo], b = fk[hi];
-          if ((a > b) == up) {
-            fk[lo] = b;
-            fk[hi] = a;
-          }
-        }
-        __syncthreads();
-      }
-    }
+    bitonic_sort_lds(fk, p.P);
     for (int i = tid; i < p.N; i += nt) y[i] = x[(uint32_t)fk[i]];
     __syncthreads();
     int32_t *t = x;

@@ -50,21 +50,7 @@ __global__ __launch_bounds__(1024) void topk_chunk_kernel(const TopkParams p) {
     keys[j] = k;
   }
   __syncthreads();
-  for (int size = 2; size <= p.P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int j = tid; j < (p.P >> 1); j += nt) {
-        const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const uint64_t a = keys[lo], b = keys[hi];
-        if ((a > b) == up) {
-          keys[lo] = b;
-          keys[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
+  bitonic_sort_lds(keys, p.P);
   const int n_chunks = gridDim.x;
   for (int j = tid; j < p.kk; j += nt) {
     const uint64_t k = keys[j];
@@ -83,25 +69,6 @@ __global__ __launch_bounds__(1024) void topk_chunk_kernel(const TopkParams p) {
 __global__ __launch_bounds__(1024) void founders_kernel(const FoundersParams p) {
   extern __shared__ __align__(16) uint64_t fk_lds[];
   founders_role(p, (int)blockIdx.x, fk_lds);
-}
-
-// ascending bitonic sort of P (power of two) 64-bit keys in LDS by the whole workgroup
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, int P) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int j = tid; j < (P >> 1); j += nt) {
-        const int lo = ((j & ~(stride - 1)) << 1) | (j & (stride - 1)), hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const uint64_t a = keys[lo], b = keys[hi];
-        if ((a > b) == up) {
-          keys[lo] = b;
-          keys[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // jax.random.permutation(key, N) into x (LDS, N int32; y is scratch of the same size; keys holds
