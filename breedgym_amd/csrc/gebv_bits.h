@@ -33,6 +33,8 @@
 
 namespace bh {
 
+constexpr int kPlaneStrideBits = 144;  // bytes from one row's 128 bytes of planes to the next in LDS (gebv_bytes.h: the same)
+
 struct GebvBitsParams {
   const uint8_t *rows;  // (n_src, row_bytes) bit-plane rows
   const int32_t *idx;   // (n_rows) source row of output row i, or null (= i)
@@ -96,17 +98,25 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
 
   // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row
   // (its lanes re-read the last row; nothing of it is used by gebv_finish_kernel)
-  const int tile0 = (rg * 4 + wave) * F;
-  const uint8_t *pa[F];
+  //
+  // How the rows are read.  The MFMA wants lane (r, h) to hold 64 bytes of row r per macro-chunk; read that way
+  // (round 2) an instruction touches 32 rows and takes a quarter of a 128-byte line from each: four requests per
+  // line at the L2.  Now an instruction takes WHOLE lines (8192 x 100k x 1: 61 -> 56 us, 2048 x 100k x 8: 31.6 -> 30.6):
+  // lane l reads piece l & 7 of row 8 i + (l >> 3), i = 0..3, and the tile of 32 x 128 bytes is turned in LDS (row
+  // stride 144: conflict-free 16-byte reads) -- written and read back by the same wave, no barrier.
+  static_assert(F == 1, "one 32-row tile per wave");
+  __shared__ __attribute__((aligned(16))) uint8_t turn[4][32 * kPlaneStrideBits];
+  const int tile0 = rg * 4 + wave;
+  const uint8_t *pa[4];  // the four rows this lane reads a piece of
 #pragma unroll
-  for (int f = 0; f < F; ++f) {
-    int row = min((tile0 + f) * 32 + r, p.n_rows - 1);
+  for (int i = 0; i < 4; ++i) {
+    int row = min(tile0 * 32 + 8 * i + (lane >> 3), p.n_rows - 1);
     if (p.idx) {
       int s = p.idx[row];
       if (s < 0) s += p.n_src;
       row = s < 0 ? 0 : (s >= p.n_src ? p.n_src - 1 : s);
     }
-    pa[f] = p.rows + (int64_t)row * p.row_bytes + 64 * h;
+    pa[i] = p.rows + (int64_t)row * p.row_bytes + 16 * (lane & 7);
   }
 
   i32x16 acc[F][NT];
@@ -120,16 +130,21 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
   struct Chunk {
     uint4 g[F][4];
   };
-  auto load_chunk = [&](int mc, Chunk &c) {
-    const int64_t off = (int64_t)mc * 128 + 64 * h;  // this lane's 64 bytes of the macro-chunk
+  auto load_chunk = [&](int mc, Chunk &c) {  // whole lines: c.g[0][i] = piece (lane & 7) of row 8 i + (lane >> 3)
+    // a 16-byte piece is wholly inside the row or wholly beyond it (row_bytes % 16 == 0)
+    const bool in = mc < mc_end && (int64_t)mc * 128 + 16 * (lane & 7) + 16 <= p.row_bytes;
 #pragma unroll
-    for (int f = 0; f < F; ++f)
+    for (int i = 0; i < 4; ++i)
+      c.g[0][i] = in ? *reinterpret_cast<const uint4 *>(pa[i] + (int64_t)mc * 128) : make_uint4(0, 0, 0, 0);
+  };
+  auto turn_chunk = [&](Chunk &c) {  // ... -> c.g[0][q] = bytes [64 h + 16 q, +16) of row r: what the MFMA phase reads
+    uint8_t *t = &turn[wave][0];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // a 16-byte piece is wholly inside the row or wholly beyond it (row_bytes % 16 == 0)
-        const bool in = mc < mc_end && off + 16 * q + 16 <= p.row_bytes;
-        c.g[f][q] = in ? *reinterpret_cast<const uint4 *>(pa[f] + (int64_t)mc * 128 + 16 * q) : make_uint4(0, 0, 0, 0);
-      }
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4 *>(t + (8 * i + (lane >> 3)) * kPlaneStrideBits + 16 * (lane & 7)) = c.g[0][i];
+    // (a wave's LDS operations are served in order: its reads below see its writes above)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.g[0][q] = *reinterpret_cast<const uint4 *>(t + r * kPlaneStrideBits + 64 * h + 16 * q);
   };
   // digit operands of stage k of this slice -> registers (NT * QS 16-byte pieces per thread)
   i32x4 breg[NT * QS];
@@ -162,7 +177,8 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
       }
     }
   };
-  auto chunk_stages = [&](int &k, const Chunk &c) {
+  auto chunk_stages = [&](int &k, Chunk &c) {
+    turn_chunk(c);
 #pragma unroll
     for (int qq = 0; qq < 4 / QS; ++qq, ++k) {
       store_b((k + 1) & 1);  // stage k+1's digits; that buffer was last read in stage k-1, before the barrier
