@@ -68,7 +68,6 @@ int sort_layout(bh_ctx *c, int64_t segs, int64_t N, int64_t rounds, SortBufs *b)
   return BH_OK;
 }
 
-// the elements in A of every segment sorted by key, stable, back into A
 // one stable pass on 8 bits of the key: in -> out (tiles of `nb` per segment; hist / tot as in `b`)
 int radix_pass(bh_ctx *c, const SortBufs &b, const uint2 *in, uint2 *out, int64_t segs, int64_t N, int shift) {
   bh::SortParams p{};
@@ -166,7 +165,7 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
   if (n_rows < 0 || n < 0 || k < 0 || k > n) return fail(BH_ERR_BAD_ARG, "bh_topk: need 0 <= k <= n");
   if (n_rows == 0 || k == 0) return BH_OK;
   if (!d_scores || !d_idx_out) return fail(BH_ERR_BAD_ARG, "bh_topk: null device pointer");
-  if (n > 0x7FFFFFFF || n_rows > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_topk: shape too large");
+  if (n > 0x3FFFFFFF || n_rows > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_topk: shape too large");
   if (k > kTopkChunk) {
     // more winners than one workgroup sorts in LDS: the whole row through the radix sort in HBM, ascending
     // ~orderable(score) (stable: ties to the lower index), and its first k
@@ -307,8 +306,8 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
   if (k < 2 || k > n) return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 2 <= k <= n");
   if (n_crosses < 1 || n_crosses > n_pairs || n_crosses > n)
     return fail(BH_ERR_BAD_ARG, "bh_selection_actions: need 1 <= n_crosses <= min(k(k-1)/2, n)");
-  if (n > 0x3FFFFFFF || n_pairs > 0x7FFFFFFF || n_envs > 65535)
-    return fail(BH_ERR_UNSUPPORTED, "bh_selection_actions: n <= 2^30, k(k-1)/2 < 2^31 and n_envs <= 65535");
+  if (n > 0x3FFFFFFF || n_pairs > 0x3FFFFFFF || n_envs > 65535)  // (element indices of the sort are 32-bit, tiles of 8192)
+    return fail(BH_ERR_UNSUPPORTED, "bh_selection_actions: n and k(k-1)/2 < 2^30, n_envs <= 65535");
   const bool in_lds = n <= 8192 && n_pairs <= 8192;  // one workgroup per env keeps everything in LDS
   const int64_t e_total = c->envs_total > 0 ? c->envs_total : n_envs, e_off = c->envs_total > 0 ? c->env_offset : 0;
   if (e_off + n_envs > e_total) return fail(BH_ERR_BAD_ARG, "more envs than the env window holds");
@@ -422,7 +421,7 @@ static int founders_device_impl(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, 
   if (n_envs * n > 0) {
     if (n_germplasm > 8192) {
       // beyond one workgroup's LDS: the shuffle rounds as radix sorts in HBM, envs side by side (sort_kernels.h)
-      if (n_germplasm > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: germplasm too large");
+      if (n_germplasm > 0x3FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: germplasm of 2^30 rows and more");
       const int rounds = shuffle_rounds_for(n_germplasm);
       for (int64_t e0 = 0; e0 < n_envs;) {
         const int64_t segs = std::min(sort_batch(n_envs, n_germplasm), n_envs - e0);

@@ -169,7 +169,7 @@ int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64
  * n.  d_scores (E, n) f32 -> d_actions (E, n, 2) int32; env_key is advanced like the wrapper's
  * `random_key` (keys[0]).  Up to n <= 8192 and k(k-1)/2 <= 8192 one workgroup per env does it all in LDS; beyond
  * (the reference's default k = n // 10 at 2048 individuals already is: 20,706 pairs; 65,536 individuals give
- * 21.5 M pairs and three shuffle rounds) the pair ranks are shuffled by radix sorts in HBM.  k(k-1)/2 < 2^31. */
+ * 21.5 M pairs and three shuffle rounds) the pair ranks are shuffled by radix sorts in HBM.  k(k-1)/2 < 2^30. */
 int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
                          int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
 
@@ -274,7 +274,7 @@ int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_
                 int32_t *out);
 
 /* The same draw made on the device, written to d_out (E, n) int32 in stream order; env_key is advanced on the
- * host.  Germplasm up to 8192 rows: one workgroup per env, Threefry + bitonic sort in LDS; larger (to 2^31 - 1
+ * host.  Germplasm up to 8192 rows: one workgroup per env, Threefry + bitonic sort in LDS; larger (below 2^30
  * rows): the shuffle rounds as stable radix sorts in HBM, envs side by side -- nothing goes through the host. */
 int bh_founders_device(bh_ctx *ctx, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm,
                        int64_t n, int32_t *d_out);
