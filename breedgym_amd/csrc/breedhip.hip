@@ -282,6 +282,8 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_scale) (void)hipFree(c->d_scale);
   if (c->d_dig16) (void)hipFree(c->d_dig16);
   if (c->d_partial) (void)hipFree(c->d_partial);
+  if (c->d_gsum) (void)hipFree(c->d_gsum);
+  if (c->d_arrived) (void)hipFree(c->d_arrived);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
   if (c->d_effsum) (void)hipFree(c->d_effsum);

@@ -91,8 +91,10 @@ struct bh_ctx {
   double *d_scale = nullptr;  // (T) 2^-s_t
   uint4 *d_dig16 = nullptr;   // (T, 3, nvec) int16 digit planes of the fixed-point effects (packed_kernels.h)
   int32_t n_chunks = 0;
-  int32_t *d_partial = nullptr;
-  int64_t partial_cap = 0;  // int32 words
+  int32_t *d_partial = nullptr;  // gebv_mfma_kernel's int32 slabs
+  int64_t partial_cap = 0;       // int32 words
+  void *d_gsum = nullptr, *d_arrived = nullptr;  // gebv_bits.h, GebvOut: 64-bit sums per (row, trait), arrivals per row group
+  int64_t gsum_cap = 0, arrived_cap = 0;         // bytes
   // top-k scratch
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};

@@ -57,6 +57,30 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
   return BH_OK;
 }
 
+// where gebv_bits_kernel / gebv_bytes_kernel leave their sums (gebv_bits.h, GebvOut): grown on demand, zero whenever
+// no launch is in flight (the last workgroup of every row group leaves it so)
+static int gebv_out(bh_ctx *c, int64_t rows, int64_t row_groups, int64_t t0, int64_t tn, float *d_gebv, bh::GebvOut *o) {
+  const int64_t sums = row_groups * 128 * bh::kGsumTraits * (int64_t)sizeof(unsigned long long);
+  const int64_t counters = row_groups * (int64_t)sizeof(uint32_t);
+  if (sums > c->gsum_cap) {
+    if (int rc = ensure_scratch(c, &c->d_gsum, &c->gsum_cap, sums)) return rc;
+    BH_HIP(hipMemsetAsync(c->d_gsum, 0, (size_t)sums, c->stream));
+  }
+  if (counters > c->arrived_cap) {
+    if (int rc = ensure_scratch(c, &c->d_arrived, &c->arrived_cap, counters)) return rc;
+    BH_HIP(hipMemsetAsync(c->d_arrived, 0, (size_t)counters, c->stream));
+  }
+  o->gsum = static_cast<unsigned long long *>(c->d_gsum);
+  o->arrived = static_cast<uint32_t *>(c->d_arrived);
+  o->scale = c->d_scale + t0;
+  o->gebv = d_gebv;
+  o->n_rows = (int32_t)rows;
+  o->T = (int32_t)tn;
+  o->Tstride = (int32_t)c->T;
+  o->t0 = (int32_t)t0;
+  return BH_OK;
+}
+
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
 constexpr int kGebvBitsWgs = 512;
@@ -66,21 +90,11 @@ constexpr int kGebvBitsWgs = 512;
 constexpr int kGebvBytesWgs = 768;  // workgroups the K slicing aims at
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
-constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
-  constexpr int F = kGebvBitsF;
-  const int64_t row_groups = (rows + 128 * F - 1) / (128 * F), rows_pad = row_groups * 128 * F;
+  constexpr int F = 1;  // 32-row tiles per wave
+  const int64_t row_groups = (rows + 128 * F - 1) / (128 * F);
   int64_t slices = std::max<int64_t>(1, std::min<int64_t>((kGebvBitsWgs + row_groups - 1) / row_groups, c->n_mc));
   const int64_t per_slice = (c->n_mc + slices - 1) / slices;
   slices = (c->n_mc + per_slice - 1) / per_slice;
-  const int64_t need = slices * rows_pad * bh::kGebvCols;
-  if (need > c->partial_cap) {
-    BH_HIP(hipStreamSynchronize(c->stream));
-    if (c->d_partial) BH_HIP(hipFree(c->d_partial));
-    c->d_partial = nullptr;
-    c->partial_cap = 0;
-    BH_HIP(hipMalloc(&c->d_partial, (size_t)need * sizeof(int32_t)));
-    c->partial_cap = need;
-  }
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;
@@ -88,11 +102,10 @@ constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
     p.rows = reinterpret_cast<const uint8_t *>(d_rows);
     p.idx = d_idx;
     p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
-    p.partial = c->d_partial;
+    if (int rc = gebv_out(c, rows, row_groups, t0, tn, d_gebv, &p.out)) return rc;
     p.row_bytes = (int64_t)16 * c->nw;
     p.n_src = (int32_t)n_src;
     p.n_rows = (int32_t)rows;
-    p.rows_pad = (int32_t)rows_pad;
     p.n_mc = c->n_mc;
     p.mc_per_slice = (int32_t)per_slice;
     p.row_groups = (int32_t)row_groups;
@@ -103,19 +116,6 @@ constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
     else
       hipLaunchKernelGGL((bh::gebv_bits_kernel<2, F>), grid, dim3(256), 0, c->stream, p);
     BH_HIP(hipGetLastError());
-    bh::GebvFinishParams f{};
-    f.partial = c->d_partial;
-    f.scale = c->d_scale + t0;
-    f.gebv = d_gebv;
-    f.rows = (int32_t)rows;
-    f.rows_pad = (int32_t)rows_pad;
-    f.slices = (int32_t)slices;
-    f.T = (int32_t)tn;
-    f.Tstride = (int32_t)c->T;
-    f.t0 = (int32_t)t0;
-    f.cols = 32 * nt;
-    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
-    BH_HIP(hipGetLastError());
   }
   return BH_OK;
 }
@@ -123,28 +123,20 @@ constexpr int kGebvBitsF = 1;  // 32-row tiles per wave
 // GEBV of byte-layout rows in one pass: planes built in LDS, then gebv_bits' matrix-core pass (gebv_bytes.h)
 int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = kGebvCols / kGebvDigits;
-  const int64_t row_groups = (rows + 127) / 128, rows_pad = row_groups * 128;
+  const int64_t row_groups = (rows + 127) / 128;
   // enough workgroups to keep ~16 KB of row loads per wave in flight on every CU: HBM-bound
   int64_t slices = std::max<int64_t>(1, std::min<int64_t>(kGebvBytesWgs / row_groups, c->n_mc));
   const int64_t per_slice = (c->n_mc + slices - 1) / slices;
   slices = (c->n_mc + per_slice - 1) / per_slice;
-  const int64_t need = slices * rows_pad * kGebvCols;
-  void *part = c->d_partial;
-  int64_t cap = c->partial_cap * (int64_t)sizeof(int32_t);
-  const int rc0 = ensure_scratch(c, &part, &cap, need * (int64_t)sizeof(int32_t));
-  c->d_partial = static_cast<int32_t *>(part);
-  c->partial_cap = cap / (int64_t)sizeof(int32_t);
-  if (rc0) return rc0;
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * kGebvDigits > 32 ? 2 : 1;
     bh::GebvBytesParams p{};
     p.rows = d_pop;
     p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
-    p.partial = c->d_partial;
+    if (int rc = gebv_out(c, rows, row_groups, t0, tn, d_gebv, &p.out)) return rc;
     p.pitch = c->pitch;
     p.n_rows = (int32_t)rows;
-    p.rows_pad = (int32_t)rows_pad;
     p.nvec = c->nvec;
     p.n_mc = c->n_mc;
     p.mc_per_slice = (int32_t)per_slice;
@@ -155,19 +147,6 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
       hipLaunchKernelGGL((bh::gebv_bytes_kernel<1>), grid, dim3(256), 0, c->stream, p);
     else
       hipLaunchKernelGGL((bh::gebv_bytes_kernel<2>), grid, dim3(256), 0, c->stream, p);
-    BH_HIP(hipGetLastError());
-    bh::GebvFinishParams f{};
-    f.partial = c->d_partial;
-    f.scale = c->d_scale + t0;
-    f.gebv = d_gebv;
-    f.rows = (int32_t)rows;
-    f.rows_pad = (int32_t)rows_pad;
-    f.slices = (int32_t)slices;
-    f.T = (int32_t)tn;
-    f.Tstride = (int32_t)c->T;
-    f.t0 = (int32_t)t0;
-    f.cols = 32 * nt;
-    hipLaunchKernelGGL(bh::gebv_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, f);
     BH_HIP(hipGetLastError());
   }
   return BH_OK;

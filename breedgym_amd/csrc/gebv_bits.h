@@ -19,8 +19,12 @@
 //         d = x - ((x >> 1) & 0x5555...)          16 two-bit dosages
 //         operand dword q = (d >> 2q) & 0x03030303   (byte b = marker q + 4b: any order will do)
 //     10 integer instructions per 16 markers and 32 rows;
-//   * the K axis is cut into slices over blockIdx.y (rows alone never fill the chip: 2048 rows are 64
-//     tiles); every slice leaves an int32 slab, gebv_finish_kernel adds the slabs.
+//   * the K axis is cut into slices (rows alone never fill the chip: 2048 rows are 64 tiles).  A wave ends by
+//     recombining the six digit sums of every (row, trait) of its tile into one 64-bit integer and adding it, with one
+//     atomic, to the row group's accumulator; the LAST workgroup of a row group to arrive (a counter per row group)
+//     scales the sums into the caller's GEBV and leaves accumulator and counter at zero for the next launch.  (Round 2
+//     wrote an int32 slab per slice and added the slabs in a second kernel: 21 MB out and back and 5 us of launch at
+//     2048 x 100k x 8.)
 //
 // Marker order inside an MFMA is whatever the lanes hold -- a sum over K does not care -- as long as
 // the digit operand is packed to match: macro-chunk mc, step q (0..3), MFMA j (0..3), lane (c, h),
@@ -34,14 +38,84 @@
 namespace bh {
 
 constexpr int kPlaneStrideBits = 144;  // bytes from one row's 128 bytes of planes to the next in LDS (gebv_bytes.h: the same)
+static_assert(32 * kPlaneStrideBits >= 33 * 32 * 4, "a wave's tile of planes also holds its tile of digit sums (gebv_tile_out)");
+
+constexpr int kGsumTraits = 16;  // 64-bit sums per row in the accumulator (a pack has <= 10 traits)
+
+// where a pass leaves its result: every wave adds its tile to `gsum`, the last workgroup of a row group writes `gebv`
+struct GebvOut {
+  unsigned long long *gsum;  // [row / 32][trait 16][row % 32] fixed-point sums, zero between launches
+  uint32_t *arrived;         // (row_groups) workgroups of the row group that have added their tiles, zero between launches
+  const double *scale;       // (T) 2^-s_t of the pack's traits
+  float *gebv;               // (n_rows, Tstride)
+  int32_t n_rows, T, Tstride, t0;
+};
+__device__ __forceinline__ int64_t gsum_index(int row, int trait) {
+  return ((int64_t)(row >> 5) * kGsumTraits + trait) * 32 + (row & 31);
+}
+
+// The wave's 32 x (32 NT) tile of digit sums (C/D layout of the 32x32 MFMAs: column = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) -> gsum.  Column 6 t + d holds digit d of trait t; trait 5 lies across
+// the two column tiles and is added in two parts.  Sums are taken modulo 2^64 (the true total fits: s_t is chosen so).
+// One atomic instruction adds 32 rows x 2 traits, the 32 rows of a trait side by side in memory: four cache lines
+// (with a row's traits side by side it is 32 lines, and the atomics cost the 2048 x 100k x 8 pass 9 us of its 37).
+// `tile`: 33 * 32 ints of LDS that belong to this wave.  Returns what the atomics returned, folded: a caller that
+// has this value has its sums in memory (gebv_group_done).
+template <int NT>
+__device__ __forceinline__ unsigned long long gebv_tile_out(const i32x16 (&acc)[NT], int32_t *tile, const GebvOut &o, int row0,
+                                                            int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  unsigned long long seen = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile[((k & 3) + 8 * (k >> 2) + 4 * h) * 33 + r] = acc[t][k];
+    // (a wave's LDS operations are served in order: the reads below see the writes above)
+    const int first = t == 0 ? 0 : 5;  // first trait with a column in this tile
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int trait = first + 3 * h + u;
+      unsigned long long s = 0;
+#pragma unroll
+      for (int d = 0; d < kGebvDigits; ++d) {
+        const int col = 6 * trait + d - 32 * t;
+        if (col >= 0 && col < 32) s += (unsigned long long)(long long)tile[r * 33 + col] << (8 * d);
+      }
+      if (trait < o.T && row0 + r < o.n_rows) seen ^= atomicAdd(&o.gsum[gsum_index(row0 + r, trait)], s);
+    }
+  }
+  return seen;
+}
+
+// Every workgroup of row group `rg` calls this after its waves' gebv_tile_out; the one that arrives last writes the
+// GEBVs of the group's 128 rows and leaves sums and counter at zero.  Order: a wave's additions have RETURNED (`seen`
+// is in its registers: they were carried out, wherever the memory system carries out atomics) before the barrier,
+// the workgroup counts itself after it; so whoever reads the counter at slices - 1 comes after every addition, and
+// reads the sums with atomics too (no cached copy).  No device-wide fence: on gfx950 that is a write-back and an
+// invalidation of the XCD's whole L2 per workgroup -- the digit operands with it -- and doubled the pass's time.
+__device__ __forceinline__ void gebv_group_done(const GebvOut &o, unsigned long long seen, int rg, int slices, int tid, int *flag) {
+  asm volatile("; additions returned: %0" ::"v"(seen));
+  __syncthreads();
+  if (tid == 0) *flag = atomicAdd(&o.arrived[rg], 1u) == (uint32_t)(slices - 1);
+  __syncthreads();
+  if (!*flag) return;
+  for (int i = tid; i < 128 * o.T; i += 256) {
+    const int row = rg * 128 + (i & 127), t = i >> 7;
+    if (row < o.n_rows) {
+      const long long v = (long long)atomicExch(&o.gsum[gsum_index(row, t)], 0ull);
+      o.gebv[(int64_t)row * o.Tstride + o.t0 + t] = (float)((double)v * o.scale[t]);
+    }
+  }
+  if (tid == 0) atomicExch(&o.arrived[rg], 0u);
+}
 
 struct GebvBitsParams {
   const uint8_t *rows;  // (n_src, row_bytes) bit-plane rows
   const int32_t *idx;   // (n_rows) source row of output row i, or null (= i)
   const i32x4 *B;       // [mc][q 4][ntile 2][j 4][lane 64] 16 int8 each
-  int32_t *partial;     // [slices][rows_pad][32 * NT] int32
+  GebvOut out;
   int64_t row_bytes;    // 16 * ceil(M / 64)
-  int32_t n_src, n_rows, rows_pad;
+  int32_t n_src, n_rows;
   int32_t n_mc;          // ceil(M / 512)
   int32_t mc_per_slice;
   int32_t row_groups, slices;  // the grid: 8 * row_groups * ceil(slices / 8) workgroups (slice_of_block)
@@ -97,7 +171,7 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
   const int n_stages = (mc_end - mc_begin) * (4 / QS);  // > 0 by construction of the grid
 
   // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row
-  // (its lanes re-read the last row; nothing of it is used by gebv_finish_kernel)
+  // (its lanes re-read the last row; gebv_tile_out adds nothing of it)
   //
   // How the rows are read.  The MFMA wants lane (r, h) to hold 64 bytes of row r per macro-chunk; read that way
   // (round 2) an instruction touches 32 rows and takes a quarter of a 128-byte line from each: four requests per
@@ -205,21 +279,9 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
     }
   }
 
-  // C/D layout of the 32x32 MFMAs: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  constexpr int COLS = 32 * NT;
-#pragma unroll
-  for (int f = 0; f < F; ++f) {
-    const int row0 = (tile0 + f) * 32;
-    if (row0 >= p.rows_pad) continue;
-    int32_t *out = p.partial + ((int64_t)slice * p.rows_pad + row0) * COLS;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = (kk & 3) + 8 * (kk >> 2) + 4 * h;
-        out[(int64_t)row * COLS + 32 * t + r] = acc[f][t][kk];
-      }
-  }
+  __shared__ int last_flag;
+  const unsigned long long seen = gebv_tile_out<NT>(acc[0], reinterpret_cast<int32_t *>(&turn[wave][0]), p.out, tile0 * 32, lane);
+  gebv_group_done(p.out, seen, rg, p.slices, tid, &last_flag);
 }
 
 }  // namespace bh

@@ -8,8 +8,8 @@
 // Here it goes through LDS: a wave packs the vectors of its 32 rows into bit-plane words (16 bytes -> 16 bits: the
 // bit 0 of every byte), stores them as a 32 x 128-byte tile of planes (row stride 144: conflict-free 16-byte reads),
 // and the MFMA phase reads its 64 bytes per lane from there instead of from memory -- the rest (six int8 digit
-// GEMMs, digit operands staged once per workgroup, K cut into slices, int32 slabs -> gebv_finish_kernel) is
-// gebv_bits_kernel's.  Rows are read once, nothing else of their size moves: HBM-bound at 2 M bytes per individual.
+// GEMMs, digit operands staged once per workgroup, K cut into slices) is
+// gebv_bits_kernel's, and so is the way out (gebv_tile_out, gebv_group_done).  Rows are read once, nothing else of their size moves: HBM-bound at 2 M bytes per individual.
 //
 // A chunk = 512 markers = 1 KB of a byte row = 128 bytes of planes.  The packing of chunk c+1 is spread over the
 // four MFMA steps of chunk c (eight rows per step), its loads are issued two steps ahead (16 KB in flight per wave).
@@ -24,9 +24,9 @@ namespace bh {
 struct GebvBytesParams {
   const uint8_t *rows;  // (n_rows, pitch) byte-layout rows
   const i32x4 *B;       // gebv_bits_kernel's digit operands: [mc][q 4][ntile 2][j 4][lane 64] 16 int8 each
-  int32_t *partial;     // [slices][rows_pad][32 * NT] int32
+  GebvOut out;
   int64_t pitch;
-  int32_t n_rows, rows_pad;
+  int32_t n_rows;
   int32_t nvec;  // 16-byte vectors per row
   int32_t n_mc, mc_per_slice;
   int32_t row_groups, slices;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
   const int mc_end = min(p.n_mc, mc_begin + p.mc_per_slice);
   const int n_chunks = mc_end - mc_begin;  // > 0 by construction of the grid
 
-  // the wave's 32 rows; a tile that reaches past the last row re-reads that row (gebv_finish_kernel ignores it)
+  // the wave's 32 rows; a tile that reaches past the last row re-reads that row (gebv_tile_out adds nothing of it)
   const int row0 = (rg * 4 + wave) * 32;
   const int last = p.n_rows - 1;
 
@@ -160,18 +160,9 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
     }
   }
 
-  // C/D layout of the 32x32 MFMAs: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  constexpr int COLS = 32 * NT;
-  if (row0 < p.rows_pad) {
-    int32_t *out = p.partial + ((int64_t)slice * p.rows_pad + row0) * COLS;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = (kk & 3) + 8 * (kk >> 2) + 4 * h;
-        out[(int64_t)row * COLS + 32 * t + r] = acc[t][kk];
-      }
-  }
+  __shared__ int last_flag;
+  const unsigned long long seen = gebv_tile_out<NT>(acc, reinterpret_cast<int32_t *>(&planes[wave][0][0]), p.out, row0, lane);
+  gebv_group_done(p.out, seen, rg, p.slices, tid, &last_flag);
 }
 
 }  // namespace bh
