@@ -81,6 +81,20 @@ static int gebv_out(bh_ctx *c, int64_t rows, int64_t row_groups, int64_t t0, int
   return BH_OK;
 }
 
+// K slices of a pass over `row_groups` row groups: as many as fill `wgs` workgroup slots, in whole eights when there
+// are eight or more -- slice s runs on XCD s % 8 (slice_of_block), 12 slices would give four XCDs twice the work of
+// the other four (8192 x 100k x 1 from byte rows: 398 us with 12 slices, 293 us with 22)
+// -- and then no more of them than it takes to keep the longest slice as short (2048 x 100k: 48 slices are 4 or 5
+// macro-chunks long, 40 slices are 5 nearly all: the same time per workgroup, fewer workgroups in each other's way;
+// no XCD gets more slices than before).
+static int64_t k_slices(int64_t row_groups, int64_t n_mc, int64_t wgs) {
+  int64_t s = std::max<int64_t>(1, std::min<int64_t>(wgs / row_groups, n_mc));
+  if (s < 8) return s;
+  s -= s % 8;
+  const int64_t longest = (n_mc + s - 1) / s;
+  return (n_mc + longest - 1) / longest;
+}
+
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
 constexpr int kGebvBitsWgs = 512;
@@ -92,9 +106,7 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
   constexpr int F = 1;  // 32-row tiles per wave
   const int64_t row_groups = (rows + 128 * F - 1) / (128 * F);
-  int64_t slices = std::max<int64_t>(1, std::min<int64_t>((kGebvBitsWgs + row_groups - 1) / row_groups, c->n_mc));
-  const int64_t per_slice = (c->n_mc + slices - 1) / slices;
-  slices = (c->n_mc + per_slice - 1) / per_slice;
+  const int64_t slices = k_slices(row_groups, c->n_mc, kGebvBitsWgs + row_groups - 1);
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;
@@ -107,7 +119,6 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
     p.n_src = (int32_t)n_src;
     p.n_rows = (int32_t)rows;
     p.n_mc = c->n_mc;
-    p.mc_per_slice = (int32_t)per_slice;
     p.row_groups = (int32_t)row_groups;
     p.slices = (int32_t)slices;
     const dim3 grid(bh::slice_grid(row_groups, slices));
@@ -125,9 +136,7 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = kGebvCols / kGebvDigits;
   const int64_t row_groups = (rows + 127) / 128;
   // enough workgroups to keep ~16 KB of row loads per wave in flight on every CU: HBM-bound
-  int64_t slices = std::max<int64_t>(1, std::min<int64_t>(kGebvBytesWgs / row_groups, c->n_mc));
-  const int64_t per_slice = (c->n_mc + slices - 1) / slices;
-  slices = (c->n_mc + per_slice - 1) / per_slice;
+  const int64_t slices = k_slices(row_groups, c->n_mc, kGebvBytesWgs);
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * kGebvDigits > 32 ? 2 : 1;
@@ -139,7 +148,6 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
     p.n_rows = (int32_t)rows;
     p.nvec = c->nvec;
     p.n_mc = c->n_mc;
-    p.mc_per_slice = (int32_t)per_slice;
     p.row_groups = (int32_t)row_groups;
     p.slices = (int32_t)slices;
     const dim3 grid(bh::slice_grid(row_groups, slices));

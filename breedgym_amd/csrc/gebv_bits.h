@@ -117,7 +117,6 @@ struct GebvBitsParams {
   int64_t row_bytes;    // 16 * ceil(M / 64)
   int32_t n_src, n_rows;
   int32_t n_mc;          // ceil(M / 512)
-  int32_t mc_per_slice;
   int32_t row_groups, slices;  // the grid: 8 * row_groups * ceil(slices / 8) workgroups (slice_of_block)
 };
 
@@ -138,6 +137,8 @@ __device__ __forceinline__ bool slice_of_block(int row_groups, int slices, int &
   slice = (i / row_groups) * 8 + (b & 7);
   return slice < slices;
 }
+// slice s of `slices` (<= n_mc) covers macro-chunks [slice_begin(s), slice_begin(s + 1)): lengths differ by one at most
+__host__ __device__ __forceinline__ int slice_begin(int s, int slices, int n_mc) { return (int)((int64_t)s * n_mc / slices); }
 // the grid that goes with it
 inline unsigned slice_grid(int64_t row_groups, int64_t slices) {
   return (unsigned)(slices < 8 ? row_groups * slices : 8 * row_groups * ((slices + 7) / 8));
@@ -166,8 +167,7 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
   const int r = lane & 31, h = lane >> 5;
   int rg, slice;
   if (!slice_of_block(p.row_groups, p.slices, rg, slice)) return;  // uniform per workgroup
-  const int mc_begin = slice * p.mc_per_slice;
-  const int mc_end = min(p.n_mc, mc_begin + p.mc_per_slice);
+  const int mc_begin = slice_begin(slice, p.slices, p.n_mc), mc_end = slice_begin(slice + 1, p.slices, p.n_mc);
   const int n_stages = (mc_end - mc_begin) * (4 / QS);  // > 0 by construction of the grid
 
   // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row

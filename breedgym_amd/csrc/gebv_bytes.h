@@ -28,7 +28,7 @@ struct GebvBytesParams {
   int64_t pitch;
   int32_t n_rows;
   int32_t nvec;  // 16-byte vectors per row
-  int32_t n_mc, mc_per_slice;
+  int32_t n_mc;
   int32_t row_groups, slices;
 };
 
@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int mc_begin = slice * p.mc_per_slice;
-  const int mc_end = min(p.n_mc, mc_begin + p.mc_per_slice);
+  const int mc_begin = slice_begin(slice, p.slices, p.n_mc), mc_end = slice_begin(slice + 1, p.slices, p.n_mc);
   const int n_chunks = mc_end - mc_begin;  // > 0 by construction of the grid
 
   // the wave's 32 rows; a tile that reaches past the last row re-reads that row (gebv_tile_out adds nothing of it)
