@@ -34,13 +34,14 @@ struct GebvBytesParams {
 
 constexpr int kPlaneStride = 144;  // bytes from one row's planes to the next in LDS
 
-// bit 0 of the 16 bytes of a genotype vector -> the vector's bit-plane word (bit i = byte i)
+// bit 0 of the 16 bytes of a genotype vector -> the vector's bit-plane word (bit i = byte i).  A dot product of four
+// 0/1 bytes with (1, 2, 4, 8) IS their nibble: v_dot4_u32_u8, one full-rate instruction per dword, the second of a
+// pair adding on with (16, 32, 64, 128)  (a multiply by a gathering constant is a quarter-rate v_mul_lo_u32).
 __device__ __forceinline__ uint32_t plane_word(const uint4 v) {
-  const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
-  uint32_t o = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) o |= (((dw[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);
-  return o;
+  constexpr uint32_t kBit0 = 0x01010101u;
+  const uint32_t lo = __builtin_amdgcn_udot4(v.y & kBit0, 0x80402010u, __builtin_amdgcn_udot4(v.x & kBit0, 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(v.w & kBit0, 0x80402010u, __builtin_amdgcn_udot4(v.z & kBit0, 0x08040201u, 0u, false), false);
+  return lo | (hi << 8);
 }
 
 template <int NT>

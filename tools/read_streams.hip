@@ -66,6 +66,49 @@ __global__ __launch_bounds__(256) void tile_coop(const uint8_t *in, uint32_t *ou
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[blockIdx.x * 256 + threadIdx.x] = acc.x;
 }
 
+// the walk as a kernel would really make it: batches of 8 loads (8 / V rows x V KB), D batches in flight, the oldest
+// consumed while the newest is issued; workgroup = 4 waves x 32 rows, K slice = [kb0, kb0 + kbs) KB
+template <int V, int D>
+__global__ __launch_bounds__(256) void tile_pipe(const uint8_t *in, uint32_t *out, int n_rows, int64_t pitch, int row_kb, int kbs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_groups = n_rows / 128;
+  const int rg = blockIdx.x % row_groups, slice = blockIdx.x / row_groups;
+  const int row0 = rg * 128 + wave * 32;
+  const int kb0 = slice * kbs, kb1 = min(row_kb, kb0 + kbs);
+  constexpr int RB = 8 / V;        // rows per batch
+  constexpr int NB = 32 / RB;      // batches per visit of the 32 rows
+  const int n_batches = (kb1 - kb0 + V - 1) / V * NB;
+  uint4 v[D][8];
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  auto issue = [&](int b, uint4(&dst)[8]) {
+    const int kb = kb0 + (b / NB) * V, rb = (b % NB) * RB;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int u = 0; u < V; ++u) {
+        const int k = min(kb + u, row_kb - 1);
+        dst[i * V + u] = b < n_batches ? *reinterpret_cast<const uint4 *>(in + (int64_t)(row0 + rb + i) * pitch + 1024 * (int64_t)k + 16 * lane)
+                                       : make_uint4(0, 0, 0, 0);
+      }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d, v[d]);
+  for (int b = 0; b < n_batches; b += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc.x ^= v[d][i].x;
+        acc.y ^= v[d][i].y;
+        acc.z ^= v[d][i].z;
+        acc.w ^= v[d][i].w;
+      }
+      issue(b + d + D, v[d]);
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[blockIdx.x * 256 + threadIdx.x] = acc.x;
+}
+
 // linear: a wave reads `seq` whole rows one after the other, 16 KB per trip
 __global__ __launch_bounds__(256) void linear(const uint8_t *in, uint32_t *out, int n_rows, int64_t pitch, int row_kb, int seq) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -98,7 +141,7 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int64_t pitch : {200704, 200000})
+  for (int64_t pitch : {200000})
   for (int n_rows : {2048, 8192}) {
     uint8_t *in;
     uint32_t *out;
@@ -125,6 +168,13 @@ int main() {
       timed("tile V=1 slices,wgs", slices, blocks, [&]() { hipLaunchKernelGGL(tile_walk<1>, dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
       timed("tile V=2 slices,wgs", slices, blocks, [&]() { hipLaunchKernelGGL(tile_walk<2>, dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
       timed("tile V=4 slices,wgs", slices, blocks, [&]() { hipLaunchKernelGGL(tile_walk<4>, dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
+    }
+    for (int kbs : {4, 5, 8, 10, 12, 16}) {  // KB of K per workgroup: 640 / 400 workgroups at 2048 rows with 5 / 8
+      const int blocks = n_rows / 128 * ((row_kb + kbs - 1) / kbs);
+      timed("pipe V=1 D=2 kbs,wgs", kbs, blocks, [&]() { hipLaunchKernelGGL((tile_pipe<1, 2>), dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
+      timed("pipe V=2 D=2 kbs,wgs", kbs, blocks, [&]() { hipLaunchKernelGGL((tile_pipe<2, 2>), dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
+      timed("pipe V=4 D=2 kbs,wgs", kbs, blocks, [&]() { hipLaunchKernelGGL((tile_pipe<4, 2>), dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
+      timed("pipe V=4 D=3 kbs,wgs", kbs, blocks, [&]() { hipLaunchKernelGGL((tile_pipe<4, 3>), dim3(blocks), dim3(256), 0, 0, in, out, n_rows, pitch, row_kb, kbs); });
     }
     for (int slices : {3, 6, 12, 24}) {
       const int kbs = (row_kb + slices - 1) / slices;
