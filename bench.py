@@ -342,7 +342,7 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
                         if obs == "eager" and committed_traffic("packed_long_kernel")[0] else None,
              "traffic_source": committed_traffic("packed_long_kernel")[1] if obs == "eager" else None,
              "gebv_pass_ms": kms_all - kms,
-             "gebv_pass_note": "gebv_bits_kernel + gebv_finish_kernel over the bit-plane offspring (0.2 GB)",
+             "gebv_pass_note": "gebv_bits_kernel over the bit-plane offspring (0.2 GB); its last workgroups write the GEBVs",
              "step_frac_of_hbm_peak": (nbytes + E * n * packed_pitch(M)) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
         if name == "eager":
             out.update(r)
@@ -372,10 +372,10 @@ def bench_c5(reps):
     return {
         "workload": "BASELINE configs[4]: GEBV of 2048 x 100k markers x 8 traits, exact int8-digit products on MFMA",
         "byte_rows": {"ms": ms_bytes, "individuals_per_s": N / (ms_bytes * 1e-3),
-                      "roofline": roofline_of("gebv_bytes_kernel<2> + gebv_finish_kernel (bh_gebv, byte-layout rows in one pass: bit planes built in LDS, digit GEMMs on the matrix cores)", N * 2 * M + eff_bytes, ms_bytes,
+                      "roofline": roofline_of("gebv_bytes_kernel<2> (bh_gebv, byte-layout rows in one pass: bit planes built in LDS, digit GEMMs on the matrix cores, 64-bit sums by atomics)", N * 2 * M + eff_bytes, ms_bytes,
                                               traffic=committed_traffic("gebv_bytes_kernel<2")[0], traffic_source=committed_traffic("gebv_bytes_kernel<2")[1])},
         "bit_planes": {"ms": ms_bits, "individuals_per_s": N / (ms_bits * 1e-3),
-                       "roofline": roofline_of("gebv_bits_kernel<2,1> + gebv_finish_kernel (bh_gather_packed, bit-plane rows)",
+                       "roofline": roofline_of("gebv_bits_kernel<2,1> (bh_gather_packed, bit-plane rows)",
                                                N * packed_pitch(M) + eff_bytes, ms_bits,
                                                traffic=committed_traffic("gebv_bits_kernel<2")[0],
                                                traffic_source=committed_traffic("gebv_bits_kernel<2")[1],

@@ -40,7 +40,7 @@ namespace bh {
 constexpr int kPlaneStrideBits = 144;  // bytes from one row's 128 bytes of planes to the next in LDS (gebv_bytes.h: the same)
 static_assert(32 * kPlaneStrideBits >= 33 * 32 * 4, "a wave's tile of planes also holds its tile of digit sums (gebv_tile_out)");
 
-constexpr int kGsumTraits = 16;  // 64-bit sums per row in the accumulator (a pack has <= 10 traits)
+constexpr int kGsumTraits = 16;  // 64-bit sums per row in the accumulator (a pack has <= 10 traits; gebv_tile_out touches slots 0..10)
 
 // where a pass leaves its result: every wave adds its tile to `gsum`, the last workgroup of a row group writes `gebv`
 struct GebvOut {
@@ -81,30 +81,44 @@ __device__ __forceinline__ unsigned long long gebv_tile_out(const i32x16 (&acc)[
         const int col = 6 * trait + d - 32 * t;
         if (col >= 0 && col < 32) s += (unsigned long long)(long long)tile[r * 33 + col] << (8 * d);
       }
-      if (trait < o.T && row0 + r < o.n_rows) seen ^= atomicAdd(&o.gsum[gsum_index(row0 + r, trait)], s);
+      // never under a condition: a lane with nothing to add adds 0 to its own slot (there are kGsumTraits slots in
+      // every row of the accumulator, rows up to the last row group's end).  Under a lane condition every atomic
+      // becomes a branch with a wait for its return behind it -- six round trips to memory in a row per tile.
+      const bool mine = trait < o.T && row0 + r < o.n_rows;
+      seen ^= atomicAdd(&o.gsum[gsum_index(row0 + r, trait)], mine ? s : 0ull);
     }
   }
   return seen;
 }
 
 // Every workgroup of row group `rg` calls this after its waves' gebv_tile_out; the one that arrives last writes the
-// GEBVs of the group's 128 rows and leaves sums and counter at zero.  Order: a wave's additions have RETURNED (`seen`
+// GEBVs of the group's rows and leaves sums and counter at zero.  Order: a wave's additions have RETURNED (`seen`
 // is in its registers: they were carried out, wherever the memory system carries out atomics) before the barrier,
 // the workgroup counts itself after it; so whoever reads the counter at slices - 1 comes after every addition, and
 // reads the sums with atomics too (no cached copy).  No device-wide fence: on gfx950 that is a write-back and an
 // invalidation of the XCD's whole L2 per workgroup -- the digit operands with it -- and doubled the pass's time.
+template <int GROUP_ROWS = 128, int THREADS = 256>
 __device__ __forceinline__ void gebv_group_done(const GebvOut &o, unsigned long long seen, int rg, int slices, int tid, int *flag) {
+  static_assert((GROUP_ROWS & (GROUP_ROWS - 1)) == 0, "rows of a row group: a power of two");
   asm volatile("; additions returned: %0" ::"v"(seen));
   __syncthreads();
   if (tid == 0) *flag = atomicAdd(&o.arrived[rg], 1u) == (uint32_t)(slices - 1);
   __syncthreads();
   if (!*flag) return;
-  for (int i = tid; i < 128 * o.T; i += 256) {
-    const int row = rg * 128 + (i & 127), t = i >> 7;
-    if (row < o.n_rows) {
-      const long long v = (long long)atomicExch(&o.gsum[gsum_index(row, t)], 0ull);
-      o.gebv[(int64_t)row * o.Tstride + o.t0 + t] = (float)((double)v * o.scale[t]);
-    }
+  // all exchanges of a thread are issued before the first is used (one after the other they are a round trip to
+  // memory each: 8 in a row held the last workgroups for 20 us)
+  constexpr int ITEMS = (GROUP_ROWS * (kGebvCols / kGebvDigits) + THREADS - 1) / THREADS;
+  long long v[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = tid + k * THREADS, row = rg * GROUP_ROWS + (i & (GROUP_ROWS - 1)), t = i / GROUP_ROWS;
+    v[k] = 0;
+    if (t < o.T && row < o.n_rows) v[k] = (long long)atomicExch(&o.gsum[gsum_index(row, t)], 0ull);
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = tid + k * THREADS, row = rg * GROUP_ROWS + (i & (GROUP_ROWS - 1)), t = i / GROUP_ROWS;
+    if (t < o.T && row < o.n_rows) o.gebv[(int64_t)row * o.Tstride + o.t0 + t] = (float)((double)v[k] * o.scale[t]);
   }
   if (tid == 0) atomicExch(&o.arrived[rg], 0u);
 }
@@ -203,19 +217,27 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
 
   struct Chunk {
     uint4 g[F][4];
+    uint32_t keep;  // all ones where this lane's pieces exist
   };
   auto load_chunk = [&](int mc, Chunk &c) {  // whole lines: c.g[0][i] = piece (lane & 7) of row 8 i + (lane >> 3)
     // a 16-byte piece is wholly inside the row or wholly beyond it (row_bytes % 16 == 0)
+    // every lane loads -- one with nothing to read takes its row's first piece and zeroes it: a load under a lane
+    // condition becomes a branch, and behind branches the compiler waits for every load in flight (gebv_bytes.h)
+    // (the zeroing waits for turn_chunk: here it would wait for the loads)
     const bool in = mc < mc_end && (int64_t)mc * 128 + 16 * (lane & 7) + 16 <= p.row_bytes;
+    const int64_t off = in ? (int64_t)mc * 128 : 0;
+    c.keep = in ? ~0u : 0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      c.g[0][i] = in ? *reinterpret_cast<const uint4 *>(pa[i] + (int64_t)mc * 128) : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) c.g[0][i] = *reinterpret_cast<const uint4 *>(pa[i] + off);
   };
   auto turn_chunk = [&](Chunk &c) {  // ... -> c.g[0][q] = bytes [64 h + 16 q, +16) of row r: what the MFMA phase reads
     uint8_t *t = &turn[wave][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4 *>(t + (8 * i + (lane >> 3)) * kPlaneStrideBits + 16 * (lane & 7)) = c.g[0][i];
+    for (int i = 0; i < 4; ++i) {
+      const uint4 v = c.g[0][i];
+      *reinterpret_cast<uint4 *>(t + (8 * i + (lane >> 3)) * kPlaneStrideBits + 16 * (lane & 7)) =
+          make_uint4(v.x & c.keep, v.y & c.keep, v.z & c.keep, v.w & c.keep);
+    }
     // (a wave's LDS operations are served in order: its reads below see its writes above)
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.g[0][q] = *reinterpret_cast<const uint4 *>(t + r * kPlaneStrideBits + 64 * h + 16 * q);

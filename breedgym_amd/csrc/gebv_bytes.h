@@ -69,21 +69,28 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[t][k] = 0;
 
-  // ---- byte rows -> registers -> planes in LDS, eight rows at a time
+  // ---- byte rows -> registers -> planes in LDS, eight rows at a time.  Every load is issued by every lane -- one
+  // that has nothing to read (past the row's end, past the slice) reads the row's first vector and its word is
+  // masked out when it is packed: a load under a lane condition becomes a branch, and behind the branches the
+  // compiler waits for ALL loads in flight (vmcnt(0)) where it should leave the younger batch alone.
   uint4 ld[2][8];
-  auto issue = [&](int chunk, int b, uint4(&dst)[8]) {  // rows 8 b .. 8 b + 7 of chunk `chunk` (wave-uniform)
+  uint32_t keep[2];  // per batch in flight: 0xFFFF where this lane's vector exists
+  auto issue = [&](int chunk, int b, int set) {  // rows 8 b .. 8 b + 7 of chunk `chunk` (wave-uniform)
     const int v = chunk * 64 + lane;
     const bool in = chunk < mc_end && v < p.nvec;
+    keep[set] = in ? 0xFFFFu : 0u;
+    const int64_t off = in ? 16 * (int64_t)v : 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = min(row0 + 8 * b + i, last);
-      dst[i] = in ? *reinterpret_cast<const uint4 *>(p.rows + (int64_t)row * p.pitch + 16 * (int64_t)v) : make_uint4(0, 0, 0, 0);
+      ld[set][i] = *reinterpret_cast<const uint4 *>(p.rows + (int64_t)row * p.pitch + off);
     }
   };
-  auto pack = [&](int buf, int b, const uint4(&src)[8]) {
+  auto pack = [&](int buf, int b, int set) {
     uint8_t *dst = &planes[wave][buf][0] + 2 * lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint16_t *>(dst + (8 * b + i) * kPlaneStride) = (uint16_t)plane_word(src[i]);
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<uint16_t *>(dst + (8 * b + i) * kPlaneStride) = (uint16_t)(plane_word(ld[set][i]) & keep[set]);
   };
 
   // ---- digit operands: global -> registers -> LDS, two stages ahead (as in gebv_bits_kernel)
@@ -117,19 +124,19 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
   };
 
   // ---- prologue: chunk 0 packed outright, the first two batches of chunk 1 under way
-  issue(mc_begin, 0, ld[0]);
-  issue(mc_begin, 1, ld[1]);
+  issue(mc_begin, 0, 0);
+  issue(mc_begin, 1, 1);
   load_b(0);
-  pack(0, 0, ld[0]);
-  issue(mc_begin, 2, ld[0]);
-  pack(0, 1, ld[1]);
-  issue(mc_begin, 3, ld[1]);
+  pack(0, 0, 0);
+  issue(mc_begin, 2, 0);
+  pack(0, 1, 1);
+  issue(mc_begin, 3, 1);
   store_b(0);
   load_b(1);
-  pack(0, 2, ld[0]);
-  issue(mc_begin + 1, 0, ld[0]);
-  pack(0, 3, ld[1]);
-  issue(mc_begin + 1, 1, ld[1]);
+  pack(0, 2, 0);
+  issue(mc_begin + 1, 0, 0);
+  pack(0, 3, 1);
+  issue(mc_begin + 1, 1, 1);
   __syncthreads();  // stage 0 of the digit operands is in LDS
 
   int k = 0;  // stage of digit operands
@@ -143,11 +150,11 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // batch q of chunk c + 1 -> planes (its loads were issued two steps ago); loads of the batch two steps on
-      if (c + 1 < n_chunks) pack(cb ^ 1, q, ld[q & 1]);
+      if (c + 1 < n_chunks) pack(cb ^ 1, q, q & 1);
       if (q < 2)
-        issue(mc_begin + c + 1, q + 2, ld[q & 1]);
+        issue(mc_begin + c + 1, q + 2, q & 1);
       else
-        issue(mc_begin + c + 2, q - 2, ld[q & 1]);
+        issue(mc_begin + c + 2, q - 2, q & 1);
       if (q % QS == 0) {
         store_b((k + 1) & 1);  // stage k+1's digits; that buffer was last read in stage k-1, before the barrier
         load_b(k + 2);
