@@ -33,6 +33,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "gebv_mfma.h"
 
 namespace bh {
@@ -169,6 +172,16 @@ __device__ __forceinline__ i32x4 dosage16_from_bits(uint32_t x) {
   return a;
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose counter is a constant in the body
+template <int... I, class Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, Fn f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 template <int NT, int F>
 __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) {
   static_assert(NT == 1 || NT == 2, "one or two 32-column tiles");
@@ -242,20 +255,23 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.g[0][q] = *reinterpret_cast<const uint4 *>(t + r * kPlaneStrideBits + 64 * h + 16 * q);
   };
-  // digit operands of stage k of this slice -> registers (NT * QS 16-byte pieces per thread)
-  i32x4 breg[NT * QS];
-  auto load_b = [&](int k) {
-    if (k < n_stages) {
-      const i32x4 *src = p.B + ((int64_t)(mc_begin * 4 + k * QS) * 2) * 256;
+  // digit operands of stage k of this slice -> registers (NT * QS 16-byte pieces per thread), kRing stages ahead of
+  // the stage that reads them from LDS: a stage is eight MFMAs long, an L2 hit under load ten times that -- asked
+  // for two stages ahead (round 2) the pass ran at the pace of its operand loads.  Stage s lives in register set
+  // s % kRing; the sets are named by constants (the loop body below is kRing stages or a multiple).
+  constexpr int kRing = 4;
+  i32x4 breg[kRing][NT * QS];
+  auto load_b = [&](int k, auto set) {
+    const int kk = min(k, n_stages - 1);  // past the slice: its last stage again, never used (no branch: load_chunk)
+    const i32x4 *src = p.B + ((int64_t)(mc_begin * 4 + kk * QS) * 2) * 256;
 #pragma unroll
-      for (int u = 0; u < QS; ++u)
+    for (int u = 0; u < QS; ++u)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) breg[u * NT + t] = src[(u * 2 + t) * 256 + tid];
-    }
+      for (int t = 0; t < NT; ++t) breg[decltype(set)::value][u * NT + t] = src[(u * 2 + t) * 256 + tid];
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, auto set) {
 #pragma unroll
-    for (int u = 0; u < NT * QS; ++u) ldsB[buf][u * 256 + tid] = breg[u];
+    for (int u = 0; u < NT * QS; ++u) ldsB[buf][u * 256 + tid] = breg[decltype(set)::value][u];
   };
   auto step = [&](int buf, int u, const Chunk &c, int q) {
 #pragma unroll
@@ -273,31 +289,34 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
       }
     }
   };
-  auto chunk_stages = [&](int &k, Chunk &c) {
+  constexpr int kChunkStages = 4 / QS;
+  static_assert((2 * kChunkStages) % kRing == 0, "the loop body (two macro-chunks) is whole turns of the ring");
+  auto chunk_stages = [&](int &k, Chunk &c, auto first) {  // `first`: this chunk's first stage, modulo kRing
     turn_chunk(c);
+    static_for<kChunkStages>([&](auto qq) {
+      const std::integral_constant<int, (decltype(first)::value + decltype(qq)::value + 1) % kRing> set;  // of stage k + 1
+      store_b((k + 1) & 1, set);  // its LDS buffer was last read in stage k-1, before the barrier
+      load_b(k + 1 + kRing, set);
 #pragma unroll
-    for (int qq = 0; qq < 4 / QS; ++qq, ++k) {
-      store_b((k + 1) & 1);  // stage k+1's digits; that buffer was last read in stage k-1, before the barrier
-      load_b(k + 2);
-#pragma unroll
-      for (int u = 0; u < QS; ++u) step(k & 1, u, c, qq * QS + u);
+      for (int u = 0; u < QS; ++u) step(k & 1, u, c, decltype(qq)::value * QS + u);
       __syncthreads();
-    }
+      ++k;
+    });
   };
 
   Chunk c0, c1;
   load_chunk(mc_begin, c0);
-  load_b(0);
-  store_b(0);
-  load_b(1);
+  static_for<kRing>([&](auto s) { load_b(decltype(s)::value, s); });
+  store_b(0, std::integral_constant<int, 0>{});
+  load_b(kRing, std::integral_constant<int, 0>{});
   __syncthreads();
   int k = 0;
   for (int mc = mc_begin; mc < mc_end; mc += 2) {
     load_chunk(mc + 1, c1);
-    chunk_stages(k, c0);
+    chunk_stages(k, c0, std::integral_constant<int, 0>{});
     if (mc + 1 < mc_end) {
       load_chunk(mc + 2, c0);
-      chunk_stages(k, c1);
+      chunk_stages(k, c1, std::integral_constant<int, kChunkStages % kRing>{});
     }
   }
 
