@@ -718,6 +718,33 @@ def test_byte_row_gebv_in_one_pass(rows, M, T, rng):
     assert gebv_close(got, co.gebv(geno, eff, want64=True)[1])
 
 
+@pytest.mark.parametrize("T", [1, 6, 10, 13])
+def test_gebv_passes_leave_their_accumulator_clean(T, rng):
+    """The matrix-core GEBV passes add 64-bit sums into one accumulator per context and count arrivals per row group
+    (csrc/gebv_bits.h: gebv_tile_out, gebv_group_done); the last workgroup of a row group leaves both at zero.  Calls
+    of different sizes, through both passes (bit planes, byte rows), growing and shrinking, one after the other on the
+    same context: every one equals the oracle.  T = 6: trait 5 lies across the two column tiles; T = 13: two packs."""
+    from breedgym_amd import HipEngine
+
+    M = 20_011
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    eff = (rng.laplace(0, 6, (M, T)) * 10.0 ** rng.integers(-2, 2, (1, T))).astype(np.float32)
+    eng = HipEngine(np.full(M, 0.01, np.float32), eff)
+    geno = (rng.random((4000, M, 2)) < 0.35).astype(np.uint8)
+    g64 = co.gebv(geno, eff, want64=True)[1]
+    rows = eng.upload_population(geno)
+    packed = eng.pack(rows)
+    for n, route in ((100, "bits"), (1000, "bits"), (37, "bits"), (4000, "bytes"), (129, "bits"), (4000, "bits"), (2000, "bytes"),
+                     (1, "bits")):
+        if route == "bits":
+            g = eng.empty((n, T), torch.float32)
+            eng.gather_packed(packed[:n].contiguous(), None, n, None, None, g)
+        else:
+            assert n * M >= 1 << 25
+            g = eng.gebv(rows[:n].contiguous())
+        assert gebv_close(g.cpu().numpy(), g64[:n]), (n, route)
+
+
 @pytest.mark.parametrize("E,n", [(1, 1), (3, 7), (4, 200), (2, 1000), (1, 1500)])
 def test_pair_actions_kernel(E, n, rng):
     """bh_pair_actions (PairScores._convert_actions in one kernel behind the top-k) against the NumPy restatement of
