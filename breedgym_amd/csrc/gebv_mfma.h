@@ -78,15 +78,19 @@ __global__ __launch_bounds__(256) void gebv_mfma_kernel(const GebvMfmaParams p) 
   // the matrix cores
   struct Chunk {
     uint4 ga[4];
+    uint32_t keep[4];  // all ones where this lane's piece exists
     i32x4 b00, b01, b10, b11;  // [ntile][mfma]
   };
   auto load = [&](int c, Chunk &k) {
     const int64_t off = (int64_t)c * 128;  // byte offset of the chunk in a row; this lane: + 64 h
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      // a 16-byte piece is either wholly inside the row or wholly beyond it (pitch % 16 == 0)
+      // a 16-byte piece is either wholly inside the row or wholly beyond it (pitch % 16 == 0).  Every lane loads -- one
+      // past the row's end its row's first piece, zeroed where it is used: a load under a lane condition is a branch,
+      // and behind branches the compiler waits for every load in flight (gebv_bytes.h)
       const bool in = off + 64 * h + 16 * q + 16 <= p.pitch;
-      k.ga[q] = in ? *reinterpret_cast<const uint4 *>(pa + off + 16 * q) : make_uint4(0, 0, 0, 0);
+      k.keep[q] = in ? ~0u : 0u;
+      k.ga[q] = *reinterpret_cast<const uint4 *>(pa + (in ? off + 16 * q : (int64_t)-64 * h));
     }
     const i32x4 *Bc = p.B + (int64_t)c * 256 + lane;
     k.b00 = Bc[0];
@@ -96,7 +100,9 @@ __global__ __launch_bounds__(256) void gebv_mfma_kernel(const GebvMfmaParams p) 
   };
   auto compute = [&](const Chunk &k) {
     // MFMA 0 sums markers 32h + 0..15 of the chunk, MFMA 1 markers 32h + 16..31 (A and B agree)
-    const i32x4 a0 = dosage16(k.ga[0], k.ga[1]), a1 = dosage16(k.ga[2], k.ga[3]);
+    i32x4 a0 = dosage16(k.ga[0], k.ga[1]), a1 = dosage16(k.ga[2], k.ga[3]);
+    a0.x &= (int)k.keep[0], a0.y &= (int)k.keep[0], a0.z &= (int)k.keep[1], a0.w &= (int)k.keep[1];
+    a1.x &= (int)k.keep[2], a1.y &= (int)k.keep[2], a1.z &= (int)k.keep[3], a1.w &= (int)k.keep[3];
     acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, k.b00, acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, k.b10, acc[1], 0, 0, 0);
     acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, k.b01, acc[0], 0, 0, 0);
