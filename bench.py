@@ -379,8 +379,8 @@ def bench_c5(reps):
                                                N * packed_pitch(M) + eff_bytes, ms_bits,
                                                traffic=committed_traffic("gebv_bits_kernel<2")[0],
                                                traffic_source=committed_traffic("gebv_bits_kernel<2")[1],
-                                               note="51 MB of rows: not bound by its bytes any more but by the int8 MFMAs and "
-                                                    "their operand build",
+                                               note="51 MB of rows: not bound by its bytes but by instruction issue -- operand build, LDS "
+                                                    "reads of the digit operands and MFMAs of two waves per SIMD (DESIGN 4d)",
                                                mfma_int8_Tops=2.0 * N * M * 64 / (ms_bits * 1e-3) / 1e12, mfma_int8_peak_Tops=5000.0),
                        "api_level_GBps": N * 2 * M / (ms_bits * 1e-3) / 1e9},
     }
