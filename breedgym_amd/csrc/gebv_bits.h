@@ -99,7 +99,9 @@ __device__ __forceinline__ unsigned long long gebv_tile_out(const i32x16 (&acc)[
 // is in its registers: they were carried out, wherever the memory system carries out atomics) before the barrier,
 // the workgroup counts itself after it; so whoever reads the counter at slices - 1 comes after every addition, and
 // reads the sums with atomics too (no cached copy).  No device-wide fence: on gfx950 that is a write-back and an
-// invalidation of the XCD's whole L2 per workgroup -- the digit operands with it -- and doubled the pass's time.
+// invalidation of the XCD's whole L2 per workgroup -- the digit operands with it -- and doubled the pass's time; a
+// release on the counter alone (the write-back, one wave per workgroup) still costs 6 to 24 us per launch
+// (profiles/r03_ab_gebv_out.txt).
 template <int GROUP_ROWS = 128, int THREADS = 256>
 __device__ __forceinline__ void gebv_group_done(const GebvOut &o, unsigned long long seen, int rg, int slices, int tid, int *flag) {
   static_assert((GROUP_ROWS & (GROUP_ROWS - 1)) == 0, "rows of a row group: a power of two");
