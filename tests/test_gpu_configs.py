@@ -745,6 +745,31 @@ def test_gebv_passes_leave_their_accumulator_clean(T, rng):
         assert gebv_close(g.cpu().numpy(), g64[:n]), (n, route)
 
 
+def test_gebv_passes_on_random_shapes():
+    """A seeded sweep of shapes through the matrix-core GEBV passes -- row counts that are no multiple of a tile or a
+    row group, marker counts that end a row inside a macro-chunk, any number of traits up to two packs: the K slicing
+    (even slices, whole eights per XCD round), the padded rows and the unused trait slots of the accumulator must never
+    show.  Bit planes always; byte rows where the population is large enough for the one-pass kernel."""
+    from breedgym_amd import HipEngine
+
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    rng = np.random.default_rng(20240607)
+    for case in range(24):
+        T = int(rng.integers(1, 13))
+        rows = int(rng.integers(1, 900)) if case % 3 else int(rng.integers(900, 2600))
+        M = int(rng.integers(16_385, 60_000))
+        eff = (rng.laplace(0, 4, (M, T)) * 10.0 ** rng.integers(-2, 3, (1, T))).astype(np.float32)
+        eng = HipEngine(np.full(M, 0.01, np.float32), eff)
+        geno = (rng.random((rows, M, 2)) < rng.uniform(0.05, 0.6)).astype(np.uint8)
+        g64 = co.gebv(geno, eff, want64=True)[1]
+        d = eng.upload_population(geno)
+        g = eng.empty((rows, T), torch.float32)
+        eng.gather_packed(eng.pack(d), None, rows, None, None, g)
+        assert gebv_close(g.cpu().numpy(), g64), ("bit planes", rows, M, T)
+        assert gebv_close(eng.gebv(d).cpu().numpy(), g64), ("byte rows", rows, M, T, rows * M >= 1 << 25)
+        del eng
+
+
 @pytest.mark.parametrize("E,n", [(1, 1), (3, 7), (4, 200), (2, 1000), (1, 1500)])
 def test_pair_actions_kernel(E, n, rng):
     """bh_pair_actions (PairScores._convert_actions in one kernel behind the top-k) against the NumPy restatement of
