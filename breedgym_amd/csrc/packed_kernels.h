@@ -322,12 +322,15 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           const uint4 oo = expand_vector(o);
           if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo;
           if constexpr (TT > 0) {
-            if (has) {  // a lane that redid the last vector must not count it twice
+            {
               typedef short short2v __attribute__((ext_vector_type(2)));
               const uint32_t ww[4] = {oo.x, oo.y, oo.z, oo.w};
               uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
+              // a lane that redid the last vector must not count it twice: its dosages are zeroed, not branched
+              // around (four branches per trip cost the configs[1] launch 0.6 of its 23.7 us)
+              const uint32_t hm = has ? 0x00FF00FFu : 0u;
 #pragma unroll
-              for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
+              for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & hm;
 #pragma unroll
               for (int q = 0; q < TT; ++q)
 #pragma unroll
