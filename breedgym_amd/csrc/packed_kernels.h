@@ -25,6 +25,19 @@ constexpr int kLongRowVectors = 4;   // vectors per lane and trip in the long-ro
 constexpr int kShortRowVectors = 2;  // ... and in the stream with GEBV
 constexpr int kLongAhead = 1, kShortAhead = 1;  // trips the stream requests ahead: without / with GEBV
 
+// the sum of `v` over the wave's 64 lanes (it forms in lane 63 and is handed to all): four DPP steps
+// inside a row of 16 lanes (two quad swaps, the half mirror, the mirror), two across rows (row_bcast15, row_bcast31)
+// -- no LDS round trips (a 64-bit __shfl_xor reduction is twelve ds_bpermute with a wait after every pair)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror: every lane of a row has the row's sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 struct PackedParams {
   const uint16_t *src;  // cross: (E, n_pool, nvp) packed pool; gather: (n_pool, nvp)
   uint16_t *outp;       // (rows, nvp) packed rows out, or null
@@ -378,10 +391,19 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-          // digits recombined in int64 per lane, then summed over the wave: exact, order-free
-          long long sum = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
+          // exact, order-free: the three digit sums are added over the wave, then recombined in int64.  Rows of up to
+          // 16384 markers (every row that has its GEBV made here when there are 32 rows or more: cross.hip,
+          // use_bits_gebv) keep a wave's digit sum inside an int32 -- 2 * 32768 * 16384 = 2^30 -- and add it with six
+          // DPP steps per digit; longer rows recombine per lane first and go through the 64-bit shuffle.
+          long long sum;
+          if (p.nvec <= 2048) {
+            sum = (long long)wave_sum_i32(acc[r][t][0]) + (long long)wave_sum_i32(acc[r][t][1]) * 65536LL +
+                  (long long)wave_sum_i32(acc[r][t][2]) * 4294967296LL;
+          } else {
+            sum = (long long)acc[r][t][0] + (long long)acc[r][t][1] * 65536LL + (long long)acc[r][t][2] * 4294967296LL;
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+          }
           if (lane == 0 && live[r]) {
             const float g = (float)((double)sum * p.scale[p.t0 + t]);
             p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
