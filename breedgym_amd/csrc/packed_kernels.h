@@ -234,6 +234,11 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   // fed and they take every issue slot it leaves (their role has no vector loads to be starved of, mask_stream.h)
   if constexpr (TT == 0) __builtin_amdgcn_s_setprio(kLongRowPrio);
   const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R * seq);
+  // the traits' scales are asked for here: read where they are used -- after the last trip, by one lane -- they cost
+  // every wave a memory round trip at the very end of its life (a microsecond of the configs[1] launch)
+  double scale[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) scale[t] = TT > 0 ? p.scale[p.t0 + t] : 0.0;
   for (int sq = 0; sq < seq; ++sq) {
     const int c0 = first + sq * R;
     if (c0 >= p.n_rows) return;
@@ -405,7 +410,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
           }
           if (lane == 0 && live[r]) {
-            const float g = (float)((double)sum * p.scale[p.t0 + t]);
+            const float g = (float)((double)sum * scale[t]);
             p.gebv[(int64_t)(c0 + r) * p.T + p.t0 + t] = g;
             if constexpr (MODE == MODE_CROSS)
               if (p.reward) reward_row(rw, p.reward, p.reward_pitch, env0, c0 + r, p.n_out, g);
