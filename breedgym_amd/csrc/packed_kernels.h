@@ -247,6 +247,18 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     uint16_t *dstp[R];
     uint8_t *dstb[R];
     bool live[R];
+    typedef const int32_t __attribute__((address_space(4))) *scalar_i32_ptr;
+    const scalar_i32_ptr sidx = (scalar_i32_ptr)(uintptr_t)p.idx;
+    int raw0[R], raw1[R];  // the rows' parent indices as the caller wrote them, all asked for before any is used
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int c = c0 + r < p.n_rows ? c0 + r : c0;
+      raw0[r] = raw1[r] = c;
+      if constexpr (MODE == MODE_CROSS) {
+        raw0[r] = sidx[2 * (int64_t)c];
+        raw1[r] = sidx[2 * (int64_t)c + 1];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       live[r] = c0 + r < p.n_rows;
@@ -257,8 +269,10 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       // with one 32-bit offset (no 64-bit address arithmetic, a third of the registers)
       if constexpr (MODE == MODE_CROSS) {
         const int e = c / p.n_out, i = c - e * p.n_out;
-        const int i0 = __builtin_amdgcn_readfirstlane(norm_index(p.idx[2 * (int64_t)c], p.n_pool));
-        const int i1 = __builtin_amdgcn_readfirstlane(norm_index(p.idx[2 * (int64_t)c + 1], p.n_pool));
+        // ... and read through the scalar cache (as packed_dma.h reads them): the pairs of the wave's R rows are
+        // asked for together and come as scalars; as vector loads each row's pair was waited for before the next
+        // row's was asked for -- a memory round trip per row before the first word load
+        const int i0 = norm_index(raw0[r], p.n_pool), i1 = norm_index(raw1[r], p.n_pool);
         src0[r] = p.src + ((int64_t)e * p.n_pool + i0) * p.nvp;
         src1[r] = p.src + ((int64_t)e * p.n_pool + i1) * p.nvp;
         Z16[r] = reinterpret_cast<const uint16_t *>(p.Z + (int64_t)(p.rng_shared ? i : c) * p.zpitch);
