@@ -161,34 +161,42 @@ int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int6
 }
 
 
+// winners from which a long row (more than one workgroup sorts whole) goes through the sort, whose four passes over a
+// row of 16 K ... 1 M scores take 83 ... 103 us whatever k: the routes below take 85 us at 512 winners of 40,000 scores,
+// 135 at 1,024, 179 at 1,025 (levels of 16384-candidate chunk sorts), 177 for 6,553 of 65,536 (radix select, one
+// workgroup per row); tools/time_topk.py
+constexpr int64_t kTopkSortMinWinners = 513;
+// top-k of every row through the radix sort in HBM: the whole row ascending by ~orderable(score) (stable: ties to the
+// lower index), and its first k
+static int topk_by_sort(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t k, int32_t *d_idx_out) {
+  for (int64_t r0 = 0; r0 < n_rows;) {
+    const int64_t segs = std::min(sort_batch(n_rows, n), n_rows - r0);
+    SortBufs b{};
+    if (int rc = sort_layout(c, segs, n, 0, &b)) return rc;
+    bh::ScoreKeyParams sp{};
+    sp.scores = d_scores + r0 * n;
+    sp.kv = b.A;
+    sp.seg_stride = b.stride;
+    sp.N = (int32_t)n;
+    hipLaunchKernelGGL(bh::score_keys_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
+                       c->stream, sp);
+    BH_HIP(hipGetLastError());
+    if (int rc = radix_sort(c, b, b.A, b.B, segs, n)) return rc;
+    hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)segs), dim3(256), 0,
+                       c->stream, b.A, b.stride, (int32_t)k, d_idx_out + r0 * k);
+    BH_HIP(hipGetLastError());
+    r0 += segs;
+  }
+  return BH_OK;
+}
+
 int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64_t k, int32_t *d_idx_out) {
   if (n_rows < 0 || n < 0 || k < 0 || k > n) return fail(BH_ERR_BAD_ARG, "bh_topk: need 0 <= k <= n");
   if (n_rows == 0 || k == 0) return BH_OK;
   if (!d_scores || !d_idx_out) return fail(BH_ERR_BAD_ARG, "bh_topk: null device pointer");
   if (n > 0x3FFFFFFF || n_rows > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_topk: shape too large");
-  if (k > kTopkChunk) {
-    // more winners than one workgroup sorts in LDS: the whole row through the radix sort in HBM, ascending
-    // ~orderable(score) (stable: ties to the lower index), and its first k
-    for (int64_t r0 = 0; r0 < n_rows;) {
-      const int64_t segs = std::min(sort_batch(n_rows, n), n_rows - r0);
-      SortBufs b{};
-      if (int rc = sort_layout(c, segs, n, 0, &b)) return rc;
-      bh::ScoreKeyParams sp{};
-      sp.scores = d_scores + r0 * n;
-      sp.kv = b.A;
-      sp.seg_stride = b.stride;
-      sp.N = (int32_t)n;
-      hipLaunchKernelGGL(bh::score_keys_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
-                         c->stream, sp);
-      BH_HIP(hipGetLastError());
-      if (int rc = radix_sort(c, b, b.A, b.B, segs, n)) return rc;
-      hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)segs), dim3(256), 0,
-                         c->stream, b.A, b.stride, (int32_t)k, d_idx_out + r0 * k);
-      BH_HIP(hipGetLastError());
-      r0 += segs;
-    }
-    return BH_OK;
-  }
+  // more winners than one workgroup sorts in LDS, or many winners of a long row: the sort
+  if (k > kTopkChunk || (n > kTopkChunk && k >= kTopkSortMinWinners)) return topk_by_sort(c, d_scores, n_rows, n, k, d_idx_out);
 
   if (!c->big_lds_set) {
     BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::topk_chunk_kernel),
