@@ -478,8 +478,8 @@ def bench_c4_one_rank(steps, warmup, barrier):
     key = np.array([0, 9], np.uint32)
     ms = time_events(lambda i: eng.selection_actions(scores, k, nc, key), max(5, steps // 4), warm=2)
     out["selection_actions"] = {"shape": f"n = {n}, k = {k} (n // 10), {k * (k - 1) // 2} pairs, n_crosses = {nc}", "ms": ms,
-                                "note": "bh_selection_actions: top-k by radix select, 3 shuffle rounds x 4 radix passes over "
-                                        "(key, value) pairs in HBM, un-ranking"}
+                                "note": "bh_selection_actions: top-k through the radix sort, 3 shuffle rounds x 4 radix passes over "
+                                        "(key, value) pairs in HBM (the last round: its front only), un-ranking"}
     return out
 
 
