@@ -40,19 +40,30 @@ struct SortParams {
 };
 
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const SortParams p) {
-  __shared__ unsigned cnt[256];
-  const int tid = threadIdx.x, tile = blockIdx.x, seg = blockIdx.y;
-  if (tid < 256) cnt[tid] = 0;
+  __shared__ unsigned cnt[kSortWaves][256];  // a count per wave: eight times fewer lanes meet in a counter
+  const int tid = threadIdx.x, wv = tid >> 6, tile = blockIdx.x, seg = blockIdx.y;
+  for (int j = tid; j < kSortWaves * 256; j += kSortThreads) (&cnt[0][0])[j] = 0;
   __syncthreads();
   const uint2 *in = p.in + (int64_t)seg * p.seg_stride;
   const int base = tile * kSortTile;
-#pragma unroll 4
+  uint32_t key[kSortItems];
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {  // every lane loads (an element past the end: the last one, not counted)
+    const int i = base + j * kSortThreads + tid;
+    key[j] = in[i < p.N ? i : p.N - 1].x;
+  }
+#pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const int i = base + j * kSortThreads + tid;
-    if (i < p.N) atomicAdd(&cnt[(in[i].x >> p.shift) & 255u], 1u);
+    if (i < p.N) atomicAdd(&cnt[wv][(key[j] >> p.shift) & 255u], 1u);
   }
   __syncthreads();
-  if (tid < 256) p.hist[((int64_t)seg * 256 + tid) * p.nb + tile] = cnt[tid];
+  if (tid < 256) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) sum += cnt[w][tid];
+    p.hist[((int64_t)seg * 256 + tid) * p.nb + tile] = sum;
+  }
 }
 
 // inclusive scan over the 256 threads of a workgroup; returns this thread's inclusive value, *total the sum
