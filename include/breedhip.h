@@ -159,7 +159,8 @@ int bh_reward_max(bh_ctx *ctx, const float *d_gebv, int64_t n_envs, int64_t per_
 /* `jax.lax.top_k(scores, k)[1]` (vec_wrappers.py:64; Simulator.select): for each of n_rows
  * score vectors of length n, the indices of the k largest in descending order, ties to the
  * lower index (order = XLA's total order of the bit patterns: -0 below +0).  d_scores (n_rows, n) f32;
- * d_idx_out (n_rows, k) int32.  Any k <= n (above 16384 winners: a radix sort of the row in HBM). */
+ * d_idx_out (n_rows, k) int32.  Any k <= n (above 16384 winners, or more than 512 of a row longer than 16384:
+ * a radix sort of the row in HBM). */
 int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64_t k,
             int32_t *d_idx_out);
 
