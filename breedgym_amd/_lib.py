@@ -113,7 +113,8 @@ SIGNATURES = {
     "bh_reward_max": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "bh_topk": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "bh_selection_actions": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _u32p, _vp]),
-    "bh_pair_actions": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "bh_pair_actions": (_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "bh_winner_layout": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "bh_optimal_haploid": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "bh_packed_pitch": (_i64, [_vp]),
     "bh_pack": (_int, [_vp, _vp, _i64, _vp]),

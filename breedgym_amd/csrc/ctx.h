@@ -2,7 +2,7 @@
 //   breedhip.hip   context, memory, settings, host key plumbing
 //   cross.hip      bh_cross*, bh_gather*, bh_pack, bh_gebv (dispatch), bh_reward_max  -- the step/reset launches
 //   gebv.hip       the matrix-core GEBV passes, bh_optimal_haploid
-//   select.hip     bh_topk, bh_selection_actions, bh_founders_device/_deferred, the radix sort in HBM
+//   select.hip     bh_topk, bh_selection_actions, bh_founders_device/_deferred, the radix sort in HBM, bh_winner_layout
 // One kernel header belongs to exactly one of them (non-template __global__ functions are defined in headers).
 #pragma once
 #include "breedhip.h"

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
       if (s < 0) s += p.n_src;
       row = s < 0 ? 0 : (s >= p.n_src ? p.n_src - 1 : s);
     }
-    pa[i] = p.rows + (int64_t)row * p.row_bytes + 16 * (lane & 7);
+    pa[i] = p.rows + (int64_t)row * p.row_bytes;  // the row's start: the piece offset is added per load (load_chunk)
   }
 
   i32x16 acc[F][NT];
@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void gebv_bits_kernel(const GebvBitsParams p) 
     // condition becomes a branch, and behind branches the compiler waits for every load in flight (gebv_bytes.h)
     // (the zeroing waits for turn_chunk: here it would wait for the loads)
     const bool in = mc < mc_end && (int64_t)mc * 128 + 16 * (lane & 7) + 16 <= p.row_bytes;
-    const int64_t off = in ? (int64_t)mc * 128 : 0;
+    // (the row's FIRST piece, whatever the lane: with the lane's own piece offset in the base a row of fewer than
+    // eight pieces -- M <= 448 -- would be read past its end, and the last row past the end of the caller's buffer)
+    const int64_t off = in ? (int64_t)mc * 128 + 16 * (lane & 7) : 0;
     c.keep = in ? ~0u : 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) c.g[0][i] = *reinterpret_cast<const uint4 *>(pa[i] + off);

@@ -219,9 +219,9 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 // the row redo the last vector, dead row slots redo row c0; the few padding words of a packed row are
 // written behind the loop), no priority raise.
 // TT = 0: no GEBV in the stream (long rows: the matrix-core pass over the packed offspring follows,
-// gebv_bits.h).  p.seq row groups per wave, one after the other: long rows are HBM-resident, and the
-// fewer row streams the chip writes at a time the better the DRAM pages are used -- 8192 streams of
-// 100k markers store at 2.4 TB/s, 2048 at 7.7 (profiles/r01_exp_long_rows_streams.txt).
+// gebv_bits.h).  p.seq row groups per wave, one after the other: that keeps the grid of a launch of many
+// long rows small enough to be resident at once (not a question of DRAM pages: stores run at the same rate for
+// 512 ... 8192 concurrent row streams, tools/store_streams.hip).
 template <int TT, int MODE, int R, bool OBS, int VPT = 1>
 __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave,
                                                    RewardLds *rw = nullptr) {

@@ -7,10 +7,11 @@
 //                         horizon launch);  above: JAX's shuffle rounds as radix sorts in HBM, envs side by side
 //   bh_selection_actions  n <= 8192 and k(k-1)/2 <= 8192: one workgroup per env in LDS (selection_actions_kernel);
 //                         above: bh_topk's routes for the k best, radix-sort shuffle of the pair ranks, un-ranking
-//   bh_pair_actions       bh_topk's routes for the n best of n x n pair scores, then one workgroup per env
+//   bh_pair_actions       bh_topk's routes for the n best of an env's pair scores, then one workgroup per env
 //                         (softmax, offspring counts, repeat: pair_score_actions_kernel)
 #include "ctx.h"
 #include "select_kernels.h"
+#include "shard_kernels.h"
 #include "sort_kernels.h"
 
 using namespace bhh;
@@ -387,10 +388,10 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
   return BH_OK;
 }
 
-int bh_pair_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n, int32_t *d_actions) {
+int bh_pair_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t row_len, int64_t n, int32_t *d_actions) {
   if (int rc = check_ctx(c)) return rc;
   if (int rc = flush_founders(c)) return rc;
-  if (n_envs < 0 || n <= 0) return fail(BH_ERR_BAD_ARG, "bh_pair_actions: bad sizes");
+  if (n_envs < 0 || n <= 0 || row_len < n) return fail(BH_ERR_BAD_ARG, "bh_pair_actions: need n >= 1 scores per env and row_len >= n");
   if (n > 16384 || n_envs > 65535) return fail(BH_ERR_UNSUPPORTED, "bh_pair_actions: n <= 16384 and n_envs <= 65535");
   if (n_envs == 0) return BH_OK;
   if (!d_scores || !d_actions) return fail(BH_ERR_BAD_ARG, "bh_pair_actions: null device pointer");
@@ -398,12 +399,13 @@ int bh_pair_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n,
   const int rc0 = ensure_scratch(c, &best, &c->best_cap, n_envs * n * 4);
   c->d_best = best;
   if (rc0) return rc0;
-  if (int rc = topk_impl(c, d_scores, n_envs, n * n, n, static_cast<int32_t *>(best))) return rc;
+  if (int rc = topk_impl(c, d_scores, n_envs, row_len, n, static_cast<int32_t *>(best))) return rc;
   bh::PairScoreParams p{};
   p.scores = d_scores;
   p.best = static_cast<const int32_t *>(best);
   p.actions = d_actions;
   p.n = (int32_t)n;
+  p.row_len = row_len;
   const size_t lds = (size_t)n * 8;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bh::pair_score_actions_kernel),
@@ -413,6 +415,32 @@ int bh_pair_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64_t n,
   const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, (n + 63) / 64 * 64));
   hipLaunchKernelGGL(bh::pair_score_actions_kernel, dim3((unsigned)n_envs), dim3(threads), lds, c->stream, p);
   BH_HIP(hipGetLastError());
+  return BH_OK;
+}
+
+int bh_winner_layout(bh_ctx *c, const int32_t *d_winners, int64_t k, int64_t n_local, int64_t world, int64_t rank,
+                     int64_t cap, int32_t *d_send_idx, int32_t *d_pos, int32_t *d_counts, const int32_t *d_pairs,
+                     int64_t n_pair_indices, int32_t *d_idx_out) {
+  if (int rc = check_ctx(c)) return rc;
+  if (k < 0 || n_local <= 0 || world <= 0 || rank < 0 || rank >= world || cap <= 0 || n_pair_indices < 0)
+    return fail(BH_ERR_BAD_ARG, "bh_winner_layout: need k >= 0, n_local, world, cap >= 1 and 0 <= rank < world");
+  if (world > bh::kMaxShardRanks) return fail(BH_ERR_UNSUPPORTED, "bh_winner_layout: at most %d ranks", bh::kMaxShardRanks);
+  if (k > 0x3FFFFFFF || n_local * world > 0x7FFFFFFFll || cap * world > 0x7FFFFFFFll)
+    return fail(BH_ERR_UNSUPPORTED, "bh_winner_layout: too many rows for 32-bit indexing");
+  if (!d_send_idx || !d_pos || !d_counts || (k > 0 && !d_winners)) return fail(BH_ERR_BAD_ARG, "bh_winner_layout: null device pointer");
+  if (n_pair_indices > 0 && (!d_pairs || !d_idx_out || k == 0)) return fail(BH_ERR_BAD_ARG, "bh_winner_layout: pairs need winners and an output");
+  bh::WinnerLayoutParams p{d_winners, d_send_idx, d_pos, d_counts, (int32_t)k, (int32_t)n_local, (int32_t)world,
+                           (int32_t)rank, (int32_t)cap};
+  const int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, round_up(k, 64)));
+  const size_t lds = (size_t)world * (1 + threads / 64) * sizeof(int32_t);
+  hipLaunchKernelGGL(bh::winner_layout_kernel, dim3(1), dim3(threads), lds, c->stream, p);
+  BH_HIP(hipGetLastError());
+  if (n_pair_indices > 0) {
+    const unsigned grid = (unsigned)std::min<int64_t>(2048, (n_pair_indices + 255) / 256);
+    hipLaunchKernelGGL(bh::remap_pairs_kernel, dim3(grid), dim3(256), 0, c->stream, d_pos, (int32_t)k, d_pairs, n_pair_indices,
+                       d_idx_out);
+    BH_HIP(hipGetLastError());
+  }
   return BH_OK;
 }
 

@@ -245,6 +245,7 @@ struct PairScoreParams {
   const int32_t *best;  // (E, n) flat indices of the n best, best first (bh_topk)
   int32_t *actions;     // (E, n, 2)
   int32_t n;
+  int64_t row_len;  // scores per env: n * n for the documented (E, n, n) action; the reference flattens whatever it is given
 };
 
 __global__ __launch_bounds__(1024) void pair_score_actions_kernel(const PairScoreParams p) {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(1024) void pair_score_actions_kernel(const PairScor
   float *ex = ps_lds;
   int32_t *ends = reinterpret_cast<int32_t *>(ps_lds + p.n);
   const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, n = p.n;
-  const float *sc = p.scores + (int64_t)e * n * n;
+  const float *sc = p.scores + (int64_t)e * p.row_len;
   const int32_t *best = p.best + (int64_t)e * n;
   const float vmax = sc[best[0]];  // best first: the largest score
   double local = 0.0;

@@ -92,10 +92,22 @@ class PackedPopulation:
         return self.unpack()[item]
 
 
+# How many owners a storage has, Python wrappers and C++ holders (a view, a DLPack capsule) alike.  A private symbol of
+# torch: looked up by name, and CHECKED (block_pool_supported) before the pool relies on it.
+_storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
+
+
 class _Blocks:
     """A set of device blocks with the views handed out of them, and a cheap test for "nobody outside still holds
     any of it": the Python reference counts of the handed-out objects and the use counts of their storages (a slice
-    or a ``view`` a caller made shares the storage) are what they were when only the pool held them."""
+    or a ``view`` a caller made shares the storage) are what they were when only the pool held them.
+
+    What this sees: the objects themselves, views / slices / ``detach()`` of them, DLPack exports
+    (``torch.utils.dlpack.to_dlpack``, ``from_dlpack`` consumers), anything that keeps the tensor object alive
+    (NumPy arrays of a CPU tensor, CuPy / Numba arrays made through ``__cuda_array_interface__``, which hold the
+    exporting object).  What it cannot see: a raw ``data_ptr()`` kept elsewhere, the bare ``__cuda_array_interface__``
+    dict without its tensor, and work a consumer enqueued on ANOTHER stream before dropping its reference (torch's
+    caching allocator has the same rule: keep the tensor, or ``record_stream``)."""
 
     def __init__(self, tensors, handed_out):
         self.storages = tuple(t.untyped_storage() for t in tensors)  # kept: their use counts include these wrappers
@@ -106,11 +118,43 @@ class _Blocks:
     def rebase(self):
         self.base = self._counts()
 
-    def _counts(self, use_count=torch._C._storage_Use_Count, refcount=sys.getrefcount):
+    def _counts(self, refcount=sys.getrefcount):
+        use_count = _storage_use_count
         return [use_count(c) for c in self.cdata] + [refcount(o) for o in self.handed_out]
 
     def free(self) -> bool:
         return self._counts() == self.base
+
+
+_pool_ok = None
+
+
+def block_pool_supported() -> bool:
+    """Whether this torch build lets ``_Blocks.free`` see every kind of holder it promises to see: checked once,
+    on CPU tensors (storages are counted the same way on every device), before the first pool is made.  A build
+    where the private use-count symbol is gone, or where a C++ owner no longer shows in either count, gets fresh
+    blocks per step (``block_pool=0`` behaviour) and a warning -- never a silently overwritten observation."""
+    global _pool_ok
+    if _pool_ok is not None:
+        return _pool_ok
+    ok = _storage_use_count is not None
+    if ok:
+        try:
+            t = torch.empty(64, dtype=torch.uint8)
+            b = _Blocks([t], [t])
+            del t  # as in StepRing._add_slot: the counts of "nobody else holds it" are taken without local names
+            b.rebase()
+            probes = (lambda x: x[3:9], lambda x: x.view(torch.int8), lambda x: x.detach(), lambda x: [x],
+                      torch.utils.dlpack.to_dlpack, lambda x: torch.from_dlpack(x), lambda x: x.numpy())
+            for hold in probes:
+                h = hold(b.handed_out[0])
+                seen = not b.free()
+                del h
+                ok = ok and seen and b.free()
+        except Exception:
+            ok = False
+    _pool_ok = ok
+    return ok
 
 
 class StepRing:
@@ -454,9 +498,18 @@ class HipEngine(EngineBase):
             _lib.check(rc)
         return outp, out, gebv, nxt
 
-    def step_ring(self, n_envs: int, n_out: int, with_observations: bool, max_slots: int = 16) -> "StepRing":
+    def step_ring(self, n_envs: int, n_out: int, with_observations: bool, max_slots: int = 16) -> Optional["StepRing"]:
         """Reusable output blocks for ``VecBreedGym.step``, bound to the context (bh_step_bind): a step then is one
-        C call with no allocation (``StepRing.step``)."""
+        C call with no allocation (``StepRing.step``).  None (= fresh blocks per step) when this torch build fails
+        ``block_pool_supported``."""
+        if not block_pool_supported():
+            import warnings
+
+            warnings.warn(
+                f"breedgym_amd: torch {torch.__version__} does not let the block pool see who still holds a block "
+                "(torch._C._storage_Use_Count is missing or no longer counts C++ owners): block_pool is off, every "
+                "step allocates fresh blocks", RuntimeWarning, stacklevel=2)
+            return None
         return StepRing(self, n_envs, n_out, with_observations, max_slots)
 
     def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None) -> None:
@@ -530,13 +583,33 @@ class HipEngine(EngineBase):
         return out, key
 
     def pair_actions(self, scores, n: int) -> torch.Tensor:
-        """``PairScores._convert_actions`` for every env (bh_pair_actions): (E, n, n) pair scores -> (E, n, 2) int32."""
+        """``PairScores._convert_actions`` for every env (bh_pair_actions): (E, ...) pair scores -> (E, n, 2) int32.
+        An env's scores are taken flat, whatever their shape (``action.flatten()``, vec_wrappers.py:102): (n, n) as
+        documented, (n, T, E, n, T) when a caller feeds ``np.add.outer`` of multi-trait GEBVs (tests/test_vec.py:198)."""
         s = scores.as_subclass(torch.Tensor) if isinstance(scores, torch.Tensor) else torch.as_tensor(np.asarray(scores))
         s = s.to(device=self.device, dtype=torch.float32).contiguous()
-        E = s.numel() // (n * n)
+        E = s.shape[0]
         out = torch.empty((E, n, 2), dtype=torch.int32, device=self.device)
-        _lib.check(self._L.bh_pair_actions(self._h, s.data_ptr(), E, int(n), out.data_ptr()))
+        _lib.check(self._L.bh_pair_actions(self._h, s.data_ptr(), E, s.numel() // max(E, 1), int(n), out.data_ptr()))
         return out
+
+    def winner_layout(self, winners, n_local: int, world: int, rank: int, cap: int, pairs=None):
+        """Population sharding (bh_winner_layout): from the replicated list of winners (k,) int32 -> (send_idx (cap,),
+        pos (k,), counts (world + 1,) [last: the largest], pairs remapped to rows of the gathered buffer or None), all
+        on the device, nothing synchronised."""
+        assert winners.dtype == torch.int32 and winners.is_contiguous()
+        k = winners.numel()
+        send = torch.empty((int(cap),), dtype=torch.int32, device=self.device)
+        pos = torch.empty((k,), dtype=torch.int32, device=self.device)
+        counts = torch.empty((int(world) + 1,), dtype=torch.int32, device=self.device)
+        out = None
+        if pairs is not None:
+            assert pairs.dtype == torch.int32 and pairs.is_contiguous() and pairs.device == self.device
+            out = torch.empty_like(pairs)
+        _lib.check(self._L.bh_winner_layout(
+            self._h, winners.data_ptr(), k, int(n_local), int(world), int(rank), int(cap), send.data_ptr(), pos.data_ptr(),
+            counts.data_ptr(), _ptr(pairs), 0 if pairs is None else pairs.numel(), _ptr(out)))
+        return send, pos, counts, out
 
     def set_threefry_layout(self, layout) -> None:
         """"original" (jax_threefry_partitionable off: what the reference's seeded tests were recorded under) or

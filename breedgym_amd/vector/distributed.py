@@ -40,6 +40,39 @@ def _world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def _device_collectives(group=None) -> bool:
+    """Whether the process group moves device tensors itself (RCCL).  Under gloo -- the CPU tests, and the rehearsal
+    of several ranks on ONE GPU, where RCCL refuses two ranks per device -- device tensors are staged through the
+    host: slow, correct, and never the measured configuration."""
+    return dist.get_backend(group) == "nccl"
+
+
+def all_gather_stacked(t: torch.Tensor, world_size: int, group=None) -> torch.Tensor:
+    """(...) on every rank -> (world_size, ...) on every rank, on t's device."""
+    t = t.as_subclass(torch.Tensor).contiguous()
+    if world_size == 1:
+        return t.unsqueeze(0)
+    if t.is_cuda and _device_collectives(group):
+        out = torch.empty((world_size, *t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out
+    host = t.cpu()
+    parts = [torch.empty_like(host) for _ in range(world_size)]
+    dist.all_gather(parts, host, group=group)
+    return torch.stack(parts).to(t.device)
+
+
+def _reduce_small(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    """all-reduce of a few numbers, in place on t's device (staged through the host under gloo)."""
+    if t.is_cuda and not _device_collectives(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 class DistributedBreedGym:
     """``num_envs = envs_per_device * world_size`` breeding programmes, ``envs_per_device`` per rank."""
 
@@ -63,8 +96,8 @@ class DistributedBreedGym:
         rank draws from them through its env window.  (seed=None on first use: rank 0's choice is broadcast.)"""
         if seed is None and self.env.random_key is None:
             t = torch.randint(0, 2**31 - 1, (1,), dtype=torch.int64)
-            if self.world_size > 1:
-                t = t.to(self.device) if self.device.type == "cuda" else t
+            if self.world_size > 1:  # a host tensor under gloo, a device tensor under RCCL
+                t = t.to(self.device) if self.device.type == "cuda" and _device_collectives(self.group) else t
                 dist.broadcast(t, src=0, group=self.group)
             seed = int(t.item())
         return self.env.reset(seed=seed, options=options)
@@ -80,11 +113,7 @@ class DistributedBreedGym:
         t = local.as_subclass(torch.Tensor).contiguous()
         if self.world_size == 1:
             return t
-        out = torch.empty((self.world_size, *t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=self.group) if t.is_cuda else dist.all_gather(
-            list(out.unbind(0)), t, group=self.group
-        )
-        return out.reshape(self.num_envs, *t.shape[1:])
+        return all_gather_stacked(t, self.world_size, self.group).reshape(self.num_envs, *t.shape[1:])
 
     def gather_rewards(self, local_rewards) -> np.ndarray:
         t = local_rewards if isinstance(local_rewards, torch.Tensor) else torch.as_tensor(np.asarray(local_rewards))
@@ -96,7 +125,7 @@ class DistributedBreedGym:
         t = local_rewards if isinstance(local_rewards, torch.Tensor) else torch.as_tensor(np.asarray(local_rewards))
         m = t.to(device=self.device, dtype=torch.float32).as_subclass(torch.Tensor).max().reshape(1)
         if self.world_size > 1:
-            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+            _reduce_small(m, dist.ReduceOp.MAX, self.group)
         return float(m.item())
 
     def close(self):
@@ -113,9 +142,15 @@ class ShardedPopulation:
     World-size invariant: with the same ``key`` on every rank and ``pairs`` = the rank's rows of one global
     (n_total, 2) pair table, the N-rank generation is the 1-rank generation of the whole population, row for
     row (the engine's cross window makes rank r use keys ``1 + 2 (r n_local + b) + p`` of one
-    ``split(key, 2 n_total + 1)``)."""
+    ``split(key, 2 n_total + 1)``).
 
-    def __init__(self, simulator, local_rows: torch.Tensor, group=None, storage: str = "bytes"):
+    No host round trip on the data path of a generation: where winners live and land is worked out on the device
+    (``bh_winner_layout``), and the one number the host needs -- how many rows the largest share has, which sizes the
+    all-gather -- is *speculated* from the generation before (``cap_slack`` above the last largest share), read back
+    from pinned memory only after the generation's cross has been queued, and the generation is redone with the
+    exact size in the (rare, tested) case the guess was too small.  The first generation sizes its blocks exactly."""
+
+    def __init__(self, simulator, local_rows: torch.Tensor, group=None, storage: str = "bytes", cap_slack: float = 0.125):
         if storage not in ("bytes", "bits"):
             raise ValueError("storage must be 'bytes' or 'bits'")
         self.sim = simulator
@@ -127,6 +162,12 @@ class ShardedPopulation:
         self._store = self.eng.pack(local_rows) if storage == "bits" else local_rows
         self.n_local = local_rows.shape[0]
         self.n_total = self.n_local * self.world_size
+        self.cap_slack = float(cap_slack)
+        self._cap_hint = None  # rows per block of the winners' all-gather, guessed for the next generation
+        self.redone = 0        # generations whose guess was too small
+        cuda = self._store.is_cuda
+        self._counts_host = torch.empty((self.world_size + 1,), dtype=torch.int32, pin_memory=cuda)
+        self._counts_ready = torch.cuda.Event() if cuda else None
 
     @property
     def rows(self) -> torch.Tensor:
@@ -134,14 +175,7 @@ class ShardedPopulation:
         return self.eng.unpack(self._store) if self.storage == "bits" else self._store
 
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world_size == 1:
-            return t.unsqueeze(0)
-        out = torch.empty((self.world_size, *t.shape), dtype=t.dtype, device=t.device)
-        if t.is_cuda:
-            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        else:
-            dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
-        return out
+        return all_gather_stacked(t, self.world_size, self.group)
 
     def _gather_local(self, src, idx, out) -> None:
         if self.storage == "bits":
@@ -157,47 +191,71 @@ class ShardedPopulation:
         return self.eng.gebv(self._store)
 
     def global_topk(self, local_scores: torch.Tensor, k: int) -> torch.Tensor:
-        """Global indices (descending score, ties to the lower global index) of the k best of the
-        whole population, identical on every rank.  Candidates: each rank's local top-min(k, n_local)."""
-        s = local_scores.as_subclass(torch.Tensor).reshape(-1).to(torch.float32)
+        """Global indices (k,) int32 (descending score, ties to the lower global index) of the k best of the
+        whole population, identical on every rank.  Candidates: each rank's local top-min(k, n_local), exchanged
+        with ONE all-gather of (score bits, global index) pairs."""
+        s = local_scores.as_subclass(torch.Tensor).reshape(-1).to(device=self._store.device, dtype=torch.float32)
         kk = min(k, self.n_local)
-        loc = self.eng.topk(s, kk).to(torch.int64)
-        cand_s = self._all_gather(s[loc])  # (W, kk)
-        cand_i = self._all_gather(loc + self.rank * self.n_local)  # (W, kk) global indices
+        loc = self.eng.topk(s, kk)
+        cand = torch.stack((s[loc.to(torch.int64)].view(torch.int32), loc + self.rank * self.n_local), dim=1)  # (kk, 2)
+        cand = self._all_gather(cand).reshape(-1, 2)  # (W kk, 2), rank-major
         # jax.lax.top_k on the concatenated scores resolves ties to the lower index.  The candidate list is
         # rank-major and, inside a rank, in the local top-k's order (ties already to the lower index), ranks own
         # ascending index ranges: the earlier position IS the lower global index, so a top-k with ties to the
         # earlier position needs no re-ordering of the candidates
-        best = self.eng.topk(cand_s.reshape(-1), k).to(torch.int64)
-        return cand_i.reshape(-1)[best]
+        best = self.eng.topk(cand[:, 0].contiguous().view(torch.float32), k).to(torch.int64)
+        return cand[:, 1][best].contiguous()
+
+    # ---- the winners' rows on every rank --------------------------------------------------------------------------
+    def _counts_to_host(self, counts: torch.Tensor) -> None:
+        if self._counts_ready is not None:
+            self._counts_host.copy_(counts, non_blocking=True)
+            self._counts_ready.record()
+        else:
+            self._counts_host.copy_(counts)
+
+    def _largest_share(self) -> int:
+        """The largest number of winners one rank owns, as the last layout call found it (waits for that call only)."""
+        if self._counts_ready is not None:
+            self._counts_ready.synchronize()
+        return int(self._counts_host[self.world_size])
+
+    def _cap_bound(self, k: int) -> int:
+        return max(1, min(k, self.n_local))
+
+    def _exact_cap(self, winners: torch.Tensor) -> int:
+        """The exact block size, at the price of one wait for the device (first generation, and after a bad guess)."""
+        _, _, counts, _ = self.eng.winner_layout(winners, self.n_local, self.world_size, self.rank, 1)
+        self._counts_to_host(counts)
+        return max(1, self._largest_share())
+
+    def _replicate(self, winners: torch.Tensor, cap: int, pairs: Optional[torch.Tensor] = None):
+        """Queue: layout -> this rank's block of `cap` rows -> one all-gather.  -> (pool (W cap, row bytes), pos (k,),
+        pairs remapped to pool rows or None).  Valid iff ``_largest_share() <= cap`` afterwards."""
+        send_idx, pos, counts, idx = self.eng.winner_layout(winners, self.n_local, self.world_size, self.rank, cap, pairs)
+        self._counts_to_host(counts)
+        block = torch.empty((cap, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
+        self._gather_local(self._store, send_idx, block)
+        pool = self._all_gather(block).reshape(self.world_size * cap, -1)
+        return pool, pos, idx
+
+    def _next_cap(self, k: int, largest: int) -> int:
+        return min(self._cap_bound(k), largest + int(largest * self.cap_slack) + 16)
 
     def replicate_winners(self, global_idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """The rows of ``global_idx`` (k,) on every rank: ``(pool, pos)`` with winner j in row ``pos[j]`` of
         ``pool`` (rows in the storage layout).
 
         Winners are owned by contiguous index ranges, and ``global_idx`` is identical on all ranks: every rank
-        counts, from that list alone, how many winners each rank owns.  Each rank gathers ITS winners (in list
-        order) into a send block padded to the largest share and ONE all-gather of those blocks replicates
-        them: (N-1)/N of the rows per rank on the wire.  The blocks are not re-ordered afterwards -- ``pos``
-        says where a winner landed -- so the only extra traffic is the padding (top-k winners spread evenly:
-        a few per cent).  One small device-to-host copy (the N counts) sizes the blocks."""
-        k = global_idx.numel()
-        if self.world_size == 1:
-            buf = torch.empty((k, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
-            self._gather_local(self._store, global_idx.to(torch.int32).contiguous(), buf)
-            return buf, torch.arange(k, device=buf.device)
-        owner = torch.div(global_idx, self.n_local, rounding_mode="floor")
-        hot = torch.nn.functional.one_hot(owner, self.world_size)  # (k, W)
-        within = (hot.cumsum(0) - hot).gather(1, owner.unsqueeze(1)).squeeze(1)  # earlier winners of the same owner
-        counts = hot.sum(0).cpu()
-        cmax = int(counts.max())
-        mine = owner == self.rank
-        send_idx = torch.zeros((cmax,), dtype=torch.int32, device=self._store.device)  # padding: row 0 again
-        send_idx[: int(counts[self.rank])] = (global_idx[mine] - self.rank * self.n_local).to(torch.int32)
-        block = torch.empty((cmax, self._store.shape[1]), dtype=torch.uint8, device=self._store.device)
-        self._gather_local(self._store, send_idx, block)
-        pool = self._all_gather(block).reshape(self.world_size * cmax, -1)
-        return pool, owner * cmax + within
+        derives, from that list alone, how many winners each rank owns and where each lands.  Each rank gathers ITS
+        winners (in list order) into a block padded to the largest share and ONE all-gather of those blocks replicates
+        them: (N-1)/N of the rows per rank on the wire.  The blocks are not re-ordered afterwards -- ``pos`` says
+        where a winner landed.  (This stand-alone form sizes its blocks exactly and so waits for the device once;
+        ``select_and_cross`` speculates instead.)"""
+        w = global_idx.as_subclass(torch.Tensor).to(torch.int32).contiguous()
+        cap = self._exact_cap(w)
+        pool, pos, _ = self._replicate(w, cap)
+        return pool, pos.to(torch.int64)
 
     def gather_rows(self, global_idx: torch.Tensor) -> torch.Tensor:
         """The genotype rows of `global_idx` (k,), in that order, replicated on every rank (byte layout)."""
@@ -211,21 +269,32 @@ class ShardedPopulation:
         ``key`` is the simulator key, THE SAME on every rank, advanced in place as one device would."""
         scores = self.gebv()[:, 0]
         best = self.global_topk(scores, k)
-        pool, pos = self.replicate_winners(best)
-        gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
-        # winner j sits in row pos[j] of the gathered buffer: point the pairs there instead of moving rows
-        idx = pos[pairs_local.to(device=pool.device, dtype=torch.int64)].to(torch.int32).reshape(1, -1, 2).contiguous()
-        # this rank's crosses are crosses [rank * n_local, ...) of ONE batch of n_total: the window is set for
-        # this call only (the simulator's engine is shared with whoever else crosses on it)
-        self.eng.set_cross_window(self.rank * self.n_local, self.n_total)
-        try:
-            if self.storage == "bits":
-                out = self.eng.empty_packed(self.n_local)
-                self.eng.cross_packed(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, None, gebv)
-            else:
-                out = self.eng.empty_population(self.n_local)
-                self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
-        finally:
-            self.eng.set_cross_window(0, 0)
+        pairs = pairs_local.as_subclass(torch.Tensor).to(device=self._store.device, dtype=torch.int32).reshape(1, -1, 2).contiguous()
+        cap = self._cap_hint if self._cap_hint is not None else self._exact_cap(best)
+        key_before = key.copy()
+        while True:
+            # winner j sits in row pos[j] of the gathered buffer: the pairs are pointed there, rows are never moved
+            pool, _, idx = self._replicate(best, cap, pairs)
+            gebv = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
+            # this rank's crosses are crosses [rank * n_local, ...) of ONE batch of n_total: the window is set for
+            # this call only (the simulator's engine is shared with whoever else crosses on it)
+            self.eng.set_cross_window(self.rank * self.n_local, self.n_total)
+            try:
+                if self.storage == "bits":
+                    out = self.eng.empty_packed(self.n_local)
+                    self.eng.cross_packed(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, None, gebv)
+                else:
+                    out = self.eng.empty_population(self.n_local)
+                    self.eng.cross(pool, 1, pool.shape[0], idx, self.n_local, key, 1, out, gebv)
+            finally:
+                self.eng.set_cross_window(0, 0)
+            # only now does the host look at the count the layout found: the device has the whole generation queued
+            largest = self._largest_share()
+            if largest <= cap:
+                break
+            self.redone += 1  # the guess was too small: some winners had no row.  Same key, exact size, again
+            key[:] = key_before
+            cap = largest
+        self._cap_hint = self._next_cap(k, largest)
         self._store = out
         return DeviceArray.wrap(gebv)

@@ -354,6 +354,8 @@ class VecBreedGym(_VectorEnvBase):
                 if self._ring is not None:
                     self._ring.close()
                 self._ring = eng.step_ring(E, n, self.observations == "eager", self.block_pool)
+                if self._ring is None:  # this torch build cannot tell who holds a block (engine.block_pool_supported)
+                    self.block_pool = 0
             slot = self._ring.take() if self._ring is not None else None
             if slot is not None:
                 ring = self._ring

@@ -108,7 +108,7 @@ class PairScores(VectorWrapper):
         if hasattr(eng, "pair_actions") and n <= 16384:  # one fused kernel behind the top-k (bh_pair_actions)
             return eng.pair_actions(_as_device_f32(actions, eng), n)
         # the same in tensor operations (engines without the kernel: the CPU test double)
-        s = _as_device_f32(actions, eng).reshape(self.num_envs, n * n)
+        s = _as_device_f32(actions, eng).reshape(self.num_envs, -1)  # action.flatten(), whatever its shape (vec_wrappers.py:102)
         best = eng.topk(s, n).to(torch.int64)  # (E, n) flat indices, best first
         vals = torch.gather(s, 1, best)
         # jax.nn.softmax in f32, spelled out so that the one order-dependent step -- the sum -- is done

@@ -174,11 +174,33 @@ int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64
 int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
                          int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
 
-/* `PairScores._convert_actions` (vec_wrappers.py:100-112) for all envs: the n best of every env's n x n pair scores
- * (jax.lax.top_k on the flattened matrix), offspring per pair = ceil(softmax(their scores) * n), pairs repeated that
- * often and cut at n.  d_scores (E, n, n) f32 -> d_actions (E, n, 2) int32, pair = (flat index // n, flat index % n).
- * The softmax is taken in f32 with its sum in f64, rounded once.  n <= 16384. */
-int bh_pair_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int32_t *d_actions);
+/* `PairScores._convert_actions` (vec_wrappers.py:100-112) for all envs: the n best of every env's pair scores
+ * (jax.lax.top_k on `action.flatten()`: row_len scores per env -- n * n for the documented (E, n, n) action, but the
+ * reference flattens whatever it is handed, e.g. the (n, T, E, n, T) block its own tests/test_vec.py:198 feeds with T
+ * traits), offspring per pair = ceil(softmax(their scores) * n), pairs repeated that often and cut at n.
+ * d_scores (E, row_len) f32 -> d_actions (E, n, 2) int32, pair = (flat index // n, flat index % n) -- beyond n - 1 for
+ * row_len > n * n, which the cross entry points clamp as JAX's gather does.
+ * The softmax is taken in f32 with its sum in f64, rounded once (XLA's f32 reduction order is not reproduced: a sum
+ * that differs in its last bit can move ceil() across an integer for a score exactly on the boundary).
+ * n <= 16384, n <= row_len < 2^30. */
+int bh_pair_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t row_len, int64_t n, int32_t *d_actions);
+
+/* Population sharding (the reference has no call to replace here -- its multi-device mode is one worker
+ * process per device with whole observations piped to a parent, vec_env.py:150-236 -- this is that role for ONE
+ * population cut row-wise over `world` ranks, rank r owning rows [r n_local, (r + 1) n_local)).  d_winners (k) int32:
+ * the global top-k's row indices, best first, identical on every rank.  The winners' rows travel by one all-gather of
+ * `cap`-row blocks; this call derives, on the device, from the list alone:
+ *   d_counts (world + 1)  winners each rank owns; [world] = the largest count.  A count above `cap` means the blocks
+ *                         were too small: nothing of this call may be used, call again with cap >= d_counts[world]
+ *   d_send_idx (cap)      local rows this rank puts into its block, in list order (padding: row 0 again)
+ *   d_pos (k)             row of winner i in the gathered (world * cap)-row buffer: owner * cap + earlier winners of
+ *                         the same owner
+ *   d_idx_out             unless n_pair_indices == 0: d_pos[d_pairs[i]] for the n_pair_indices parent indices of this
+ *                         rank's crosses (indices into the winners' list; JAX's retrieval rule on k) -- what bh_cross*
+ *                         then reads the gathered buffer with.  Rows are never permuted. */
+int bh_winner_layout(bh_ctx *ctx, const int32_t *d_winners, int64_t k, int64_t n_local, int64_t world, int64_t rank,
+                     int64_t cap, int32_t *d_send_idx, int32_t *d_pos, int32_t *d_counts, const int32_t *d_pairs,
+                     int64_t n_pair_indices, int32_t *d_idx_out);
 
 /* ---- bit-plane storage behind the byte-layout API ------------
  * The observation format of the reference stays what it is -- (rows, M, 2) one byte per allele

@@ -289,3 +289,25 @@ def optimal_population_value(pop, effects, n, F=0.0, block_start=None):
         G = optimal_haploid_pop(pop[indices], effects, block_start)
     assert np.count_nonzero(output) == n
     return output
+
+
+def winner_layout(winners, n_local, world, rank, cap, pairs=None):
+    """Population sharding (no counterpart in the reference, whose multi-device mode pipes whole observations,
+    breedgym/vector/vec_env.py:150-236; include/breedhip.h, bh_winner_layout): from the replicated list of winners
+    (global row indices, best first), rank r owning rows [r n_local, (r + 1) n_local) ->
+    (send_idx (cap,), pos (k,), counts (world + 1,), idx_out or None), in plain array operations."""
+    w = np.asarray(winners, np.int64).reshape(-1)
+    owner = np.clip(w // n_local, 0, world - 1)
+    hot = owner[:, None] == np.arange(world)[None, :]
+    within = (np.cumsum(hot, axis=0) - hot)[np.arange(len(w)), owner] if len(w) else np.zeros(0, np.int64)
+    counts = hot.sum(0)
+    send = np.zeros(cap, np.int32)
+    mine = (owner == rank) & (within < cap)
+    send[within[mine]] = (w[mine] - rank * n_local).astype(np.int32)
+    pos = (owner * cap + np.minimum(within, cap - 1)).astype(np.int32)
+    out = None
+    if pairs is not None:
+        j = np.asarray(pairs, np.int64)
+        j = np.clip(np.where(j < 0, j + len(w), j), 0, len(w) - 1)  # JAX's retrieval rule on the k winners
+        out = pos[j].astype(np.int32)
+    return send, pos, np.append(counts, counts.max(initial=0)).astype(np.int32), out

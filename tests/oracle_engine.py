@@ -192,5 +192,13 @@ class OracleEngine(EngineBase):
         a, key = co.selection_actions(s, k, n_crosses, env_key)
         return torch.from_numpy(a), key
 
+    def winner_layout(self, winners, n_local, world, rank, cap, pairs=None):
+        from oracle import numpy_oracle as no
+
+        send, pos, counts, out = no.winner_layout(winners.numpy(), n_local, world, rank, cap,
+                                                  None if pairs is None else pairs.numpy())
+        return (torch.from_numpy(send), torch.from_numpy(pos), torch.from_numpy(counts),
+                None if out is None else torch.from_numpy(out.reshape(pairs.shape)))
+
     def sync(self):
         pass

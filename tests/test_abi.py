@@ -32,6 +32,9 @@ def test_ctypes_table_matches_header(native_lib):
 
 def test_version_and_errors(native_lib):
     assert b"gfx950" in native_lib.bh_version()
+    import breedgym_amd
+
+    assert breedgym_amd.__version__.encode() in native_lib.bh_version()  # one version: the package's is the library's
     # argument validation happens before any device work, so it is testable without a GPU
     out = ctypes.c_void_p()
     r = np.zeros(4, np.float32)

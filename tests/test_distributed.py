@@ -1,6 +1,10 @@
 """CPU: the N > 1 paths under gloo with world_size 2 (one process per "GPU"; the engine is the
 oracle-backed test double).  Env-sharded stepping has no collective; the population-sharded
-generation uses all-gathers for top-k candidates and selected parents."""
+generation uses all-gathers for top-k candidates and selected parents.
+
+The workers take the engine as a parameter: tests/test_gpu_distributed.py runs the SAME assertions with the HIP
+engine, two ranks sharing one GPU (gloo carrying the device tensors through the host: RCCL refuses two ranks per
+device)."""
 import os
 import socket
 import sys
@@ -30,9 +34,18 @@ def _setup(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _env_sharded_worker(rank, world, port, q, env_rng="shared"):
-    _setup(rank, world, port)
+def _engine_kw(engine_kind, gm):
+    """engine=... for Simulator / the envs: the oracle-backed double, or nothing (= the HIP engine on cuda:0)."""
+    if engine_kind == "hip":
+        torch.cuda.set_device(0)
+        return {}
     from oracle_engine import OracleEngine
+
+    return {"engine": OracleEngine(gm.recombination_vec, gm.marker_effects)}
+
+
+def _env_sharded_worker(rank, world, port, q, env_rng="shared", engine_kind="oracle"):
+    _setup(rank, world, port)
 
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
     from breedgym_amd.vector import SelectionScores
@@ -43,7 +56,7 @@ def _env_sharded_worker(rank, world, port, q, env_rng="shared"):
     geno = synthetic_genotypes(N, M, seed=2)
     E = 3 * world
     env = DistributedBreedGym(3, geno, individual_per_gen=8, genetic_map=gm, reward_shaping=True, env_rng=env_rng,
-                              engine=OracleEngine(gm.recombination_vec, gm.marker_effects))
+                              **_engine_kw(engine_kind, gm))
     assert env.num_envs == E and env.local_slice() == slice(3 * rank, 3 * rank + 3)
     pop, _ = env.reset(seed=10)  # the same seed on every rank
     # WORLD-SIZE INVARIANCE: what ONE VecBreedGym of 3 * world envs computes, this rank's envs of it
@@ -69,7 +82,8 @@ def _env_sharded_worker(rank, world, port, q, env_rng="shared"):
     # the selection wrapper draws its pair shuffles through the same env window
     w = SelectionScores(env.env, k=4, n_crosses=5)
     scores = co.gebv(ref, gm.marker_effects)[..., 0]
-    low = np.asarray(w._convert_actions(scores[env.local_slice()]))
+    low = w._convert_actions(scores[env.local_slice()])
+    low = low.cpu().numpy() if isinstance(low, torch.Tensor) else np.asarray(low)
     ref_low, ref_env_key = co.selection_actions(scores, 4, 5, env_key)
     assert np.array_equal(low, ref_low[env.local_slice()]) and np.array_equal(env.env.random_key, ref_env_key)
     q.put((rank, allr.tolist(), best))
@@ -77,9 +91,8 @@ def _env_sharded_worker(rank, world, port, q, env_rng="shared"):
     dist.destroy_process_group()
 
 
-def _pop_sharded_worker(rank, world, port, q, storage="bytes"):
+def _pop_sharded_worker(rank, world, port, q, storage="bytes", engine_kind="oracle"):
     _setup(rank, world, port)
-    from oracle_engine import OracleEngine
 
     from breedgym_amd.simulator import Simulator
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
@@ -90,7 +103,7 @@ def _pop_sharded_worker(rank, world, port, q, storage="bytes"):
     geno = synthetic_genotypes(N, M, seed=2).view(np.uint8)  # the whole population, known to the test only
     n_local = N // world
     mine = slice(rank * n_local, (rank + 1) * n_local)
-    sim = Simulator(genetic_map=gm, engine=OracleEngine(gm.recombination_vec, gm.marker_effects), seed=0)
+    sim = Simulator(genetic_map=gm, seed=0, **_engine_kw(engine_kind, gm))
     rows = sim.engine.upload_population(geno[mine])
     sp = ShardedPopulation(sim, rows, storage=storage)
     scores_all = co.gebv(geno, gm.marker_effects)[:, 0]
@@ -98,28 +111,33 @@ def _pop_sharded_worker(rank, world, port, q, storage="bytes"):
     scores_all[5] = scores_all[6]  # and inside a shard
     for k in (1, 5, 13, n_local, n_local + 4):
         got = sp.global_topk(torch.from_numpy(scores_all[mine].copy()), k)
-        assert np.array_equal(got.numpy(), co.topk(scores_all, k)), k
+        assert np.array_equal(got.cpu().numpy(), co.topk(scores_all, k)), k
     best = sp.global_topk(sp.gebv()[:, 0], 9)
     parents = sp.gather_rows(best)
-    assert np.array_equal(parents.numpy()[:, : 2 * M].reshape(9, M, 2), geno[best.numpy()])
-    # WORLD-SIZE INVARIANCE over two generations: the same key on every rank, every rank's rows of one global
+    assert np.array_equal(parents.cpu().numpy()[:, : 2 * M].reshape(9, M, 2), geno[best.cpu().numpy()])
+    # WORLD-SIZE INVARIANCE over four generations: the same key on every rank, every rank's rows of one global
     # pair table -> the generation one device would compute for the whole population, row for row
     key = co.key_from_seed(100).copy()
     ref, refkey = geno, co.key_from_seed(100)
-    for gen in range(2):
+    for gen in range(4):
         pairs_global = np.random.default_rng(gen).integers(0, 9, (N, 2), dtype=np.int32)
+        if gen == 0:
+            assert sp._cap_hint is None  # the first generation sizes its blocks exactly
+        elif gen == 2:
+            sp._cap_hint = 1  # a guess that is too small: the generation is redone with the exact size, same results
         g = sp.select_and_cross(9, torch.from_numpy(pairs_global[mine]), key)
+        assert sp.redone == (1 if gen >= 2 else 0) and sp._cap_hint >= 1
         true_best = co.topk(co.gebv(ref, gm.marker_effects)[:, 0], 9)
         out, refkey = co.cross(ref[true_best][None], pairs_global[None], gm.recombination_vec, refkey, 1)
         ref = out[0]
-        assert np.array_equal(sp.rows.numpy()[:, : 2 * M].reshape(n_local, M, 2), ref[mine]), (rank, gen)
+        assert np.array_equal(sp.rows.cpu().numpy()[:, : 2 * M].reshape(n_local, M, 2), ref[mine]), (rank, gen)
         assert np.array_equal(key, refkey) and np.allclose(np.asarray(g), co.gebv(ref[mine], gm.marker_effects))
     q.put((rank, best.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(worker, world=2, extra=()):
+def _run(worker, world=2, extra=(), join_s=120):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -127,7 +145,7 @@ def _run(worker, world=2, extra=()):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(join_s)
     for p in procs:
         if p.is_alive():
             p.kill()

@@ -1,0 +1,57 @@
+"""GPU: the N > 1 paths with the HIP engine and TWO ranks -- two child processes sharing device 0, the process group
+over gloo (RCCL refuses two ranks on one device; gloo moves the device tensors through the host, see
+vector/distributed.py).  The workers and every assertion are tests/test_distributed.py's: N ranks == one device, row
+for row, against the oracle's whole-population result -- env-sharded stepping in both key modes with the selection
+wrapper's shuffles through the env window; the population-sharded generation (device-side winner layout, speculative
+block size incl. the redo of a bad guess, winners by one all-gather, cross window) in both storages with cross-shard
+ties.  What this cannot show is RCCL moving the bytes: that needs more than one GPU (bench.py --gpus N).
+
+Also: bh_winner_layout against its NumPy restatement."""
+import numpy as np
+import pytest
+import torch
+
+from test_distributed import _env_sharded_worker, _pop_sharded_worker, _run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("env_rng", ["shared", "independent"])
+def test_env_sharded_two_ranks_on_one_gpu(env_rng):
+    out = _run(_env_sharded_worker, extra=(env_rng, "hip"), join_s=420)
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("storage", ["bytes", "bits"])
+def test_population_sharded_two_ranks_on_one_gpu(storage):
+    out = _run(_pop_sharded_worker, extra=(storage, "hip"), join_s=420)
+    assert out[0][1] == out[1][1]
+
+
+@pytest.mark.parametrize("k,n_local,world,cap", [(1, 5, 1, 1), (9, 20, 2, 5), (9, 20, 2, 1), (819, 1024, 8, 140), (1500, 700, 3, 700),
+                                                 (6553, 8192, 8, 900), (6553, 8192, 8, 50), (65536, 8192, 8, 8192),
+                                                 (5000, 64, 256, 40)])
+def test_winner_layout_kernel(k, n_local, world, cap, rng):
+    from breedgym_amd import HipEngine
+    from oracle import numpy_oracle as no
+
+    eng = HipEngine(np.full(64, 0.01, np.float32), np.ones((64, 1), np.float32))
+    winners = rng.permutation(n_local * world)[:k].astype(np.int32)
+    if k > 100:  # an uneven split: most winners on two ranks
+        heavy = rng.integers(0, min(2, world), k // 2) * n_local + rng.integers(0, n_local, k // 2)
+        winners[: k // 2] = heavy.astype(np.int32)
+    pairs = rng.integers(-k - 3, k + 3, (n_local, 2)).astype(np.int32)
+    w_d, p_d = torch.from_numpy(winners).to(eng.device), torch.from_numpy(pairs).to(eng.device)
+    for rank in sorted({0, world // 2, world - 1}):
+        send, pos, counts, idx = eng.winner_layout(w_d, n_local, world, rank, cap, p_d)
+        r_send, r_pos, r_counts, r_idx = no.winner_layout(winners, n_local, world, rank, cap, pairs)
+        assert np.array_equal(counts.cpu().numpy(), r_counts), rank
+        if r_counts[world] <= cap:  # everything has a place: all of it must agree
+            assert np.array_equal(send.cpu().numpy(), r_send) and np.array_equal(pos.cpu().numpy(), r_pos)
+            assert np.array_equal(idx.cpu().numpy(), r_idx)
+        else:  # blocks too small: only the counts are promised (the caller redoes the call), but nothing may be out of range
+            assert int(pos.max()) < world * cap and int(send.max()) < n_local and int(send.min()) >= 0
+    send, pos, counts, idx = eng.winner_layout(w_d, n_local, world, 0, cap)
+    assert idx is None and np.array_equal(counts.cpu().numpy(), no.winner_layout(winners, n_local, world, 0, cap)[2])

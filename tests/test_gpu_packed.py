@@ -317,6 +317,30 @@ def test_block_pool_equals_fresh_blocks(observations, rng):
         pool.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))
         used.add(pool._prows.data_ptr())
     assert len(pool._ring.slots) == before and len(used) <= 3, (before, len(used))
+    # holders that are not torch views: a DLPack capsule, a DLPack consumer, an object exporting
+    # __cuda_array_interface__ that keeps its tensor (what CuPy / Numba arrays do) -- the slot stays out of use
+    if observations == "eager":
+        class Exported:  # a consumer of __cuda_array_interface__: the pointer AND the exporting object
+            def __init__(self, t):
+                self.owner, self.iface = t, t.as_subclass(torch.Tensor).__cuda_array_interface__
+
+        holds = (("capsule", lambda o, g: torch.utils.dlpack.to_dlpack(o.as_subclass(torch.Tensor).view(torch.uint8))),
+                 ("consumer", lambda o, g: torch.from_dlpack(g.as_subclass(torch.Tensor))),
+                 ("interface", lambda o, g: Exported(g)))
+        for kind, hold in holds:
+            o, _, _, _, i = pool.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))
+            o0, g0 = np.asarray(o).view(np.uint8).copy(), np.asarray(i["GEBV"]).copy()
+            ptr_o = o.data_ptr()
+            h = hold(o, i["GEBV"])
+            del o, i
+            for _ in range(6):
+                pool.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))
+                assert pool._populations.data_ptr() != ptr_o, kind  # the held slot is not written again
+            if kind == "capsule":
+                assert np.array_equal(torch.from_dlpack(h).cpu().numpy(), o0)
+            else:
+                assert np.array_equal((h if kind == "consumer" else h.owner).as_subclass(torch.Tensor).cpu().numpy(), g0), kind
+            del h
     # a wrapper may replace the populations (breeding_programs_env.py:56): the next step reads them
     fresh.reset(seed=4)
     pool.reset(seed=4)
