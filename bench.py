@@ -4,6 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode envs|population]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both spellings work for N > 1: started as plain ``python bench.py --gpus N`` (no RANK in the environment) this
+process becomes the launcher -- it starts N fresh child ranks of itself BEFORE anything here touches the GPU (child
+processes, never an exec), relays rank 0's JSON line and exits non-zero if any rank does.  Ranks talk over RCCL
+(backend "nccl"), one rank per GPU.  ``--oversubscribe`` lets N exceed the GPUs of the box: ranks then share devices
+and the process group runs over gloo (RCCL refuses two ranks per device) -- a rehearsal of the N-rank code path on one
+GPU, marked as such in the line, never a scaling number.
+
 Workload (N = 1, default mode): BASELINE.json configs[1] -- a 370-individual x 10k-marker synthetic
 germplasm, 16 envs x 256 individuals = 4096 crosses per generation, GEBV reward every step, episodes
 of 10 generations with autoreset (so every 10th step also pays a reset, as in the reference's
@@ -386,7 +393,7 @@ def bench_c5(reps):
     }
 
 
-def population_generation(steps, warmup, rank, world, local_rank, use_dist, barrier):
+def population_generation(steps, warmup, rank, world, local_rank, use_dist, barrier, all_reduce=None, seen=None):
     """BASELINE configs[3]: one population sharded row-wise, 8192 x 100k per rank, k = n_total // 10.  Returns the
     JSON line of the population mode (rank 0; None elsewhere)."""
     import torch
@@ -427,12 +434,15 @@ def population_generation(steps, warmup, rank, world, local_rank, use_dist, barr
     barrier()
     t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    distributed = seen(dt) if seen is not None else None
     if rank != 0:
         return None
     pp = packed_pitch(M)
     return {
+        **({"distributed": distributed} if distributed else {}),
+        "generations_redone": sp.redone,  # winners' blocks guessed too small (vector/distributed.py): 0 in a steady run
         "metric": "crosses/sec (population-sharded generation: top-k GEBV selection + crosses) at 8192 x 100k markers per GPU",
         "value": world * steps * n_local / dt_max, "unit": "crosses/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True,
@@ -453,8 +463,8 @@ def population_generation(steps, warmup, rank, world, local_rank, use_dist, barr
     }
 
 
-def bench_population(args, rank, world, local_rank, use_dist, barrier):
-    line = population_generation(args.steps, args.warmup, rank, world, local_rank, use_dist, barrier)
+def bench_population(args, rank, world, local_rank, use_dist, barrier, all_reduce, seen):
+    line = population_generation(args.steps, args.warmup, rank, world, local_rank, use_dist, barrier, all_reduce, seen)
     if line is not None:
         print(json.dumps(line), flush=True)
 
@@ -483,6 +493,54 @@ def bench_c4_one_rank(steps, warmup, barrier):
     return out
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (this process has
+    not touched the GPU and never will), wait, relay rank 0's one JSON line.  -> exit code."""
+    import socket
+    import subprocess
+
+    import torch  # counting devices does not initialise the GPU (no context is created)
+
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        print("bench.py needs a GPU: breedgym_amd has no CPU fallback", file=sys.stderr)
+        return 2
+    backend = "nccl"
+    if n > ndev:
+        if not args.oversubscribe:
+            print(f"--gpus {n} but this box has {ndev} GPU(s); --oversubscribe rehearses the {n}-rank path with ranks "
+                  f"sharing devices over gloo (not a scaling measurement)", file=sys.stderr)
+            return 2
+        backend = "gloo"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [sys.executable, str(ROOT / "bench.py")] + [a for a in sys.argv[1:]]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_BACKEND=backend, BENCH_SELF_LAUNCHED="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0's stdout carries the line; the other ranks' goes to stderr
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:  # a rank that outlives rank 0 by minutes is stuck: end it (its own pid)
+            p.kill()
+            codes.append(p.wait())
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if any(codes) or not lines:
+        sys.stderr.write(out.decode())
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,17 +555,24 @@ def main():
                     help="run only that extra configuration (profiling runs: one configuration per kernel name)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the rocprofv3 --pmc child passes behind roofline.traffic (committed passes are named instead)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than GPUs (ranks share devices, gloo instead of RCCL): a rehearsal of the "
+                         "N-rank path, not a measurement")
+    ap.add_argument("--long-steps", type=int, default=2000,
+                    help="further timed steps behind the --steps sample, reported as value_long (0: none)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.traffic_child:
         traffic_child()
         return
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))  # before this process imports torch.cuda or touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # HBM traffic of the hot kernels from PMC counters, by child processes, BEFORE this process initialises the GPU
     if (world == 1 and args.mode == "envs" and not args.headline_only and args.only is None and not args.no_live_traffic
@@ -522,8 +587,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: breedgym_amd has no CPU fallback")
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank)
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run or by self_launch (also with one rank)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -532,7 +600,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -545,8 +616,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_reduce(t, op):  # a few numbers on the device; gloo takes them through the host
+        if use_dist and backend == "nccl":
+            dist.all_reduce(t, op=op)
+        elif use_dist:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        return t
+
+    def what_the_ranks_saw(dt):
+        """-> the 'distributed' object of the line: who took part and how long each rank's timed region was."""
+        if not use_dist:
+            return None
+        ones = all_reduce(torch.ones(1, dtype=torch.float64, device=f"cuda:{local_rank}"), dist.ReduceOp.SUM)
+        lo = all_reduce(torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}"), dist.ReduceOp.MIN)
+        hi = all_reduce(torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}"), dist.ReduceOp.MAX)
+        d = {"backend": "nccl (RCCL)" if backend == "nccl" else "gloo (device tensors staged through the host)",
+             "ranks_seen": int(ones.item()), "world_size": world, "devices_on_box": torch.cuda.device_count(),
+             "launcher": "bench.py self-launch" if os.environ.get("BENCH_SELF_LAUNCHED") else "torch.distributed.run",
+             "rank_seconds_min": float(lo.item()), "rank_seconds_max": float(hi.item())}
+        if world > torch.cuda.device_count():
+            d["oversubscribed"] = (f"{world} ranks share {torch.cuda.device_count()} GPU(s): a rehearsal of the code path; "
+                                   f"the value below is NOT a {world}-GPU measurement")
+        return d
+
     if args.mode == "population":
-        bench_population(args, rank, world, local_rank, use_dist, barrier)
+        bench_population(args, rank, world, local_rank, use_dist, barrier, all_reduce, what_the_ranks_saw)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -588,10 +684,15 @@ def main():
 
     env.reset(seed=100)
     dt, t_issue = time_steps(env, actions, args.steps, args.warmup, barrier)
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = all_reduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    distributed = what_the_ranks_saw(dt)
+    # a long sample behind the driver's: the same loop for --long-steps further steps in the same process, so that a
+    # reader can see the short sample (the driver's --steps 20 is 0.5 ms) is not luck.  `value` stays on --steps.
+    dt_long = None
+    if args.long_steps > 0:
+        dt_l, _ = time_steps(env, actions, args.long_steps, 0, barrier)
+        dt_long = float(all_reduce(torch.tensor([dt_l], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
     crosses_per_step = N_ENVS * N_PER_ENV
     kern_ms = time_cross_launches(env, actions, max(20, args.steps))
 
@@ -603,9 +704,7 @@ def main():
         env_i.simulator.engine.set_env_window(rank * N_ENVS, world * N_ENVS)
         env_i.reset(seed=100)
         dt_i, _ = time_steps(env_i, actions, args.steps, args.warmup, barrier)
-        ti = torch.tensor([dt_i], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+        ti = all_reduce(torch.tensor([dt_i], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
         kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
         del env_i
 
@@ -667,6 +766,9 @@ def main():
                 kernel_crosses_per_s=crosses_per_step / (kern_ms * 1e-3),
                 step_frac_of_hbm_peak=nbytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBPS,
             ),
+            **({"value_long": world * args.long_steps * crosses_per_step / dt_long, "steps_long": args.long_steps,
+                "ms_per_step_long": dt_long / args.long_steps * 1e3} if dt_long else {}),
+            **({"distributed": distributed} if distributed else {}),
             "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "settle_s": SETTLE_S,  # untimed steps for that long before the W warm-up steps (clock settling)
         }

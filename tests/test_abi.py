@@ -89,3 +89,19 @@ def test_host_rng_golden(native_lib, golden_dir):
     f, k = hrng.founders(hrng.key(7), 4, 370, 200)
     assert np.array_equal(f, z["founders"]) and np.array_equal(k, z["founders_key"])
     assert np.array_equal(hrng.permutation(hrng.key(5), 70000)[:64], z["perm70000_head"])
+
+
+def test_bench_launcher_is_loud_without_a_gpu():
+    """`python bench.py --gpus 2` on a box without a GPU: the launcher says so and exits non-zero (it starts no rank)."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    ROOT = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "needs a GPU" in r.stderr and r.stdout.strip() == ""

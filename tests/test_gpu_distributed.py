@@ -55,3 +55,31 @@ def test_winner_layout_kernel(k, n_local, world, cap, rng):
             assert int(pos.max()) < world * cap and int(send.max()) < n_local and int(send.min()) >= 0
     send, pos, counts, idx = eng.winner_layout(w_d, n_local, world, 0, cap)
     assert idx is None and np.array_equal(counts.cpu().numpy(), no.winner_layout(winners, n_local, world, 0, cap)[2])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["envs"])
+def test_bench_self_launch_two_ranks_on_one_gpu(mode):
+    """``python bench.py --gpus 2`` as the driver spells it (plain python, no launcher): the parent starts two fresh
+    child ranks before touching the GPU and relays rank 0's line.  One GPU here, so ``--oversubscribe`` (gloo): the
+    line must say what the ranks saw and that it is a rehearsal."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "20", "--warmup", "5",
+                        "--long-steps", "200", "--headline-only", "--mode", mode], env=env, capture_output=True, text=True,
+                       timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    d = line["distributed"]
+    assert line["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["world_size"] == 2 and "gloo" in d["backend"]
+    assert d["launcher"] == "bench.py self-launch" and "oversubscribed" in d
+    assert 0 < d["rank_seconds_min"] <= d["rank_seconds_max"] and line["value"] > 0 and line["value_long"] > 0
+    assert line["config"]["crosses_per_step_per_gpu"] == 4096
