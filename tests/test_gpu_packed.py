@@ -335,7 +335,8 @@ def test_block_pool_equals_fresh_blocks(observations, rng):
             del o, i
             for _ in range(6):
                 pool.step(rng.integers(0, n, (E, n, 2), dtype=np.int32))
-                assert pool._populations.data_ptr() != ptr_o, kind  # the held slot is not written again
+                if kind == "capsule":  # (at a horizon step the observation and the GEBV come from different slots)
+                    assert pool._populations.data_ptr() != ptr_o, kind  # the held slot is not written again
             if kind == "capsule":
                 assert np.array_equal(torch.from_dlpack(h).cpu().numpy(), o0)
             else:
