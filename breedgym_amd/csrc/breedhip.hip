@@ -21,6 +21,9 @@ int check_ctx(const bh_ctx *c) {
   if (e != hipSuccess) return fail(BH_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
   if (c->h_err) {
     const uint32_t w = *static_cast<volatile uint32_t *>(c->h_err);
+    if (w == 0x53500001u)  // shuffle_sparse.h, kSpErrBucket
+      return fail(BH_ERR_HIP, "an earlier draw (bh_founders_device / bh_selection_actions) met a bucket of more than 32768 "
+                              "equal top halves among its Threefry words: its result, and every result since, is not to be trusted");
     if (w)
       return fail(BH_ERR_HIP, "an earlier launch reported a device-side error (code %u: a mask hand-off wait ran out); "
                               "its crossover masks, and every result since, are not to be trusted", w);

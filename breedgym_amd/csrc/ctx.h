@@ -115,6 +115,7 @@ struct bh_ctx {
   } ring;
   bool big_lds_set = false;
   bool select_lds_set = false;
+  bool sparse_lds_set = false;
   // device-side error word: host memory the kernels can write (a hand-off wait that ran out, row_kernels.h)
   uint32_t *h_err = nullptr, *d_err = nullptr;
 };

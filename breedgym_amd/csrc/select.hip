@@ -12,6 +12,7 @@
 #include "ctx.h"
 #include "select_kernels.h"
 #include "shard_kernels.h"
+#include "shuffle_sparse.h"
 #include "sort_kernels.h"
 
 using namespace bhh;
@@ -100,17 +101,11 @@ int shuffle_rounds_for(int64_t n) {  // jax/_src/random.py `_shuffle`
 }
 
 // jax.random.permutation(key_e, N)[:take] for envs [env_first, env_first + segs) of E_total, key_e = split(env_key,
-// E_total + 1)[1 + e], side by side as the values of the first `take` elements of every segment of *result (b.A or
-// b.B, segment stride b.stride).
-//
-// Only the front of the last round's order is wanted, and a long list (k(k-1)/2 = 21.5 M pair ranks for 8192 crosses
-// at BASELINE configs[3]) is not worth sorting whole for it: the last round runs ONE pass on the top byte of its keys
-// (stable, like the others), which leaves the elements grouped by that byte; the host reads how many fall into the
-// first groups (a 1 KB copy per segment: the one synchronisation of the call), and only that front -- the groups that
-// hold the `take` smallest keys, ~N/256 elements -- is sorted completely.  Three of the round's four passes shrink
-// to almost nothing.
+// E_total + 1)[1 + e], side by side as the values of the first `take` elements of every segment of *result (b.A,
+// segment stride b.stride): every round a full stable radix sort of all N elements.  The route of draws that want
+// (nearly) all of a long list; everything else goes through shuffle_front_sparse.
 int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int64_t env_first, int64_t segs, int64_t N,
-                     int rounds, int64_t take, const SortBufs &b, const uint2 **result) {
+                     int rounds, const SortBufs &b, const uint2 **result) {
   *result = b.A;
   bh::ShuffleKeyParams kp{};
   kp.subkeys = b.sub;
@@ -134,31 +129,151 @@ int shuffle_segments(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int6
   gp.layout = c->layout;
   const int64_t per_seg = c->layout == bh::LAYOUT_PARTITIONABLE ? N : (N + 1) / 2;
   const dim3 grid((unsigned)((per_seg + 255) / 256), (unsigned)segs);
-  const bool front_only = N >= ((int64_t)1 << 20) && take * 64 <= N;
   for (int rd = 0; rd < std::max(rounds, 1); ++rd) {  // N = 1: no round, the identity
     gp.round = rd;
     gp.init = rd == 0;
     hipLaunchKernelGGL(bh::shuffle_gen_kernel, grid, dim3(256), 0, c->stream, gp);
     BH_HIP(hipGetLastError());
     if (rounds == 0) break;
-    if (rd + 1 < rounds || !front_only) {
-      if (int rc = radix_sort(c, b, b.A, b.B, segs, N)) return rc;
-      continue;
-    }
-    if (int rc = radix_pass(c, b, b.A, b.B, segs, N, 24)) return rc;  // grouped by the top byte, in b.B
-    std::vector<uint32_t> tot((size_t)segs * 256);
-    BH_HIP(hipMemcpyAsync(tot.data(), b.tot, tot.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    BH_HIP(hipStreamSynchronize(c->stream));
-    int64_t front = 0;  // the longest front any segment needs
-    for (int64_t sg = 0; sg < segs; ++sg) {
-      int64_t run = 0;
-      for (int d = 0; d < 256 && run < take; ++d) run += tot[(size_t)sg * 256 + d];
-      front = std::max(front, run);
-    }
-    if (int rc = radix_sort(c, b, b.B, b.A, segs, front)) return rc;
-    *result = b.B;
+    if (int rc = radix_sort(c, b, b.A, b.B, segs, N)) return rc;
   }
   return BH_OK;
+}
+
+// ---- the wanted-only shuffle (shuffle_sparse.h) -------------------------------------------------------------
+// Which draws take it: lists beyond one workgroup's LDS, up to 2^25 elements (a bucket then holds 512 on average),
+// and -- above 2^18 elements, where a bucket is no longer a handful -- only when a sixteenth of the list or less is
+// wanted (a wave per wanted element looks through its whole bucket).
+bool sparse_route(int64_t N, int64_t take) {
+  return N > 8192 && N <= ((int64_t)1 << 25) && take >= 1 && (N <= ((int64_t)1 << 18) || take * 16 <= N);
+}
+
+struct SparseGeom {
+  int32_t chunk_items, nchunk, reduce_batch, nchunk_pad;  // sparse_reduce_kernel's BATCH; rows incl. its padding
+  int64_t take_stride, list_stride, per_seg_bytes;
+};
+
+SparseGeom sparse_geom(int64_t segs, int64_t N, int64_t take, int layout) {
+  SparseGeom g{};
+  const int64_t items = bh::sparse_items(layout, (int)N);
+  const int64_t max_items = layout == bh::LAYOUT_PARTITIONABLE ? bh::kSpMaxPositions : bh::kSpMaxPositions / 2;
+  const int64_t target = std::max<int64_t>(1, 512 / std::max<int64_t>(1, segs));  // ~two rounds of workgroups on 256 CUs
+  g.chunk_items = (int32_t)std::min(max_items, std::max<int64_t>(2048, (items + target - 1) / target));
+  g.nchunk = (int32_t)((items + g.chunk_items - 1) / g.chunk_items);
+  const int rows = (g.nchunk + 15) / 16;
+  g.reduce_batch = rows <= 1 ? 1 : rows <= 4 ? 4 : 12;
+  g.nchunk_pad = 16 * (int32_t)round_up(rows, g.reduce_batch);
+  g.take_stride = round_up(take, 64);
+  g.list_stride = round_up(N, 64);
+  g.per_seg_bytes = (int64_t)g.nchunk_pad * bh::kSpBuckets * 2 + (int64_t)(2 * bh::kSpBuckets + bh::kSpGroups) * 4 + bh::kSpBuckets / 8 +
+                    5 * g.take_stride * 4 + g.list_stride * 8 + g.take_stride * 8 + 16 * 256;
+  return g;
+}
+
+// segments one batch draws side by side: about 1 GB of scratch at most
+int64_t sparse_batch(int64_t segs, int64_t N, int64_t take, int layout) {
+  const SparseGeom g = sparse_geom(1, N, take, layout);
+  return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(segs, 65535), ((int64_t)1 << 30) / g.per_seg_bytes));
+}
+
+// permutation(key_e, N)[:take] as shuffle_segments, by the wanted-only route: *result (segs, *stride) elements whose
+// .y are the values.  Nothing is synchronised; a bucket over the limit leaves a code in the device error word.
+int shuffle_front_sparse(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int64_t env_first, int64_t segs, int64_t N,
+                         int rounds, int64_t take, const uint2 **result, int64_t *stride) {
+  const SparseGeom g = sparse_geom(segs, N, take, c->layout);
+  const int64_t sub_bytes = round_up(segs * std::max(rounds, 1) * 8, 256);
+  void *base = c->d_sort;
+  const int rc0 = ensure_scratch(c, &base, &c->sort_cap, segs * g.per_seg_bytes + sub_bytes + 4096);
+  c->d_sort = base;
+  if (rc0) return rc0;
+  char *q = static_cast<char *>(base);
+  auto carve = [&](int64_t bytes) {
+    char *r = q;
+    q += round_up(bytes, 256);
+    return r;
+  };
+  bh::SparseParams p{};
+  uint32_t *sub = reinterpret_cast<uint32_t *>(carve(sub_bytes));
+  p.subkeys = sub;
+  p.partial = reinterpret_cast<uint16_t *>(carve(segs * (int64_t)g.nchunk_pad * bh::kSpBuckets * 2));
+  p.list = reinterpret_cast<uint2 *>(carve(segs * g.list_stride * 8));
+  p.out = reinterpret_cast<uint2 *>(carve(segs * g.take_stride * 8));
+  p.total = reinterpret_cast<uint32_t *>(carve(segs * (int64_t)bh::kSpBuckets * 4));
+  p.pre16 = reinterpret_cast<uint32_t *>(carve(segs * (int64_t)bh::kSpBuckets * 4));
+  p.group_sum = reinterpret_cast<uint32_t *>(carve(segs * (int64_t)bh::kSpGroups * 4));
+  p.marks = reinterpret_cast<uint32_t *>(carve(segs * (int64_t)bh::kSpBuckets / 8));
+  uint32_t *want[2] = {reinterpret_cast<uint32_t *>(carve(segs * take * 4)), reinterpret_cast<uint32_t *>(carve(segs * take * 4))};
+  p.wbucket = reinterpret_cast<uint32_t *>(carve(segs * take * 4));
+  p.wrank = reinterpret_cast<uint32_t *>(carve(segs * take * 4));
+  p.wstart = reinterpret_cast<uint32_t *>(carve(segs * take * 4));
+  p.err = c->d_err;
+  p.list_stride = g.list_stride;
+  p.out_stride = g.take_stride;
+  p.N = (int32_t)N;
+  p.take = (int32_t)take;
+  p.nchunk = g.nchunk;
+  p.nchunk_pad = g.nchunk_pad;
+  p.chunk_items = g.chunk_items;
+  p.rounds = rounds;
+  p.layout = c->layout;
+
+  bh::ShuffleKeyParams kp{};
+  kp.subkeys = sub;
+  kp.key0 = env_key[0];
+  kp.key1 = env_key[1];
+  kp.segs = (int32_t)segs;
+  kp.rounds = rounds;
+  kp.layout = c->layout;
+  kp.E_total = (int32_t)E_total;
+  kp.env_first = (int32_t)env_first;
+  hipLaunchKernelGGL(bh::shuffle_subkeys_kernel, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, c->stream, kp);
+  BH_HIP(hipGetLastError());
+
+  constexpr size_t kHistLds = (size_t)bh::kSpLdsWords * 4, kGatherLds = kHistLds + bh::kSpBuckets / 8;
+  if (!c->sparse_lds_set) {
+    BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::sparse_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
+    BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::sparse_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGatherLds));
+    c->sparse_lds_set = true;
+  }
+  const dim3 chunks((unsigned)g.nchunk, (unsigned)segs);
+  for (int rd = rounds - 1, cur = 0; rd >= 0; --rd, cur ^= 1) {  // the last round first: its front is what is wanted
+    p.round = rd;
+    p.want = rd == rounds - 1 ? nullptr : want[cur ^ 1];
+    p.next_want = want[cur];
+    hipLaunchKernelGGL(bh::sparse_hist_kernel, chunks, dim3(bh::kSpThreads), kHistLds, c->stream, p);
+    {
+      const dim3 blocks(bh::kSpBuckets / 256, (unsigned)segs);
+      if (g.reduce_batch == 1)
+        hipLaunchKernelGGL(bh::sparse_reduce_kernel<1>, blocks, dim3(1024), 0, c->stream, p);
+      else if (g.reduce_batch == 4)
+        hipLaunchKernelGGL(bh::sparse_reduce_kernel<4>, blocks, dim3(1024), 0, c->stream, p);
+      else
+        hipLaunchKernelGGL(bh::sparse_reduce_kernel<12>, blocks, dim3(1024), 0, c->stream, p);
+    }
+    hipLaunchKernelGGL(bh::sparse_map_kernel, dim3((unsigned)((take + 255) / 256), (unsigned)segs), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(bh::sparse_gather_kernel, chunks, dim3(bh::kSpThreads), kGatherLds, c->stream, p);
+    hipLaunchKernelGGL(bh::sparse_select_kernel, dim3((unsigned)((take + 3) / 4), (unsigned)segs), dim3(256), 0, c->stream, p);
+    BH_HIP(hipGetLastError());
+  }
+  *result = p.out;
+  *stride = g.take_stride;
+  return BH_OK;
+}
+
+// The front of every env's shuffle by whichever route fits: `segs` envs from env_first on, at most *done of them (one
+// batch of scratch); *result / *stride as above.
+int shuffle_front(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, int64_t env_first, int64_t segs_left, int64_t N,
+                  int64_t take, const uint2 **result, int64_t *stride, int64_t *done) {
+  const int rounds = shuffle_rounds_for(N);
+  if (rounds > 0 && sparse_route(N, take)) {
+    *done = std::min(sparse_batch(segs_left, N, take, c->layout), segs_left);
+    return shuffle_front_sparse(c, env_key, E_total, env_first, *done, N, rounds, take, result, stride);
+  }
+  *done = std::min(sort_batch(segs_left, N), segs_left);
+  SortBufs b{};
+  if (int rc = sort_layout(c, *done, N, rounds, &b)) return rc;
+  *stride = b.stride;
+  return shuffle_segments(c, env_key, E_total, env_first, *done, N, rounds, b, result);
 }
 
 
@@ -361,18 +476,15 @@ int bh_selection_actions(bh_ctx *c, const float *d_scores, int64_t n_envs, int64
       c->d_best = best;
       if (rc0) return rc0;
       if (int rc = topk_impl(c, d_scores, n_envs, n, k, static_cast<int32_t *>(best))) return rc;
-      const int rounds = shuffle_rounds_for(n_pairs);
       for (int64_t e0 = 0; e0 < n_envs;) {
-        const int64_t segs = std::min(sort_batch(n_envs, n_pairs), n_envs - e0);
-        SortBufs b{};
-        if (int rc = sort_layout(c, segs, n_pairs, rounds, &b)) return rc;
         const uint2 *perm = nullptr;
-        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_pairs, rounds, n_crosses, b, &perm)) return rc;
+        int64_t stride = 0, segs = 0;
+        if (int rc = shuffle_front(c, env_key, e_total, e_off + e0, n_envs - e0, n_pairs, n_crosses, &perm, &stride, &segs)) return rc;
         bh::PairActionParams q{};
         q.perm = perm;
         q.best = static_cast<const int32_t *>(best) + e0 * k;
         q.actions = d_actions + e0 * n * 2;
-        q.seg_stride = b.stride;
+        q.seg_stride = stride;
         q.n = (int32_t)n;
         q.k = (int32_t)k;
         q.n_offspring = (int32_t)((n + n_crosses - 1) / n_crosses);
@@ -458,15 +570,12 @@ static int founders_device_impl(bh_ctx *c, uint32_t env_key[2], int64_t n_envs, 
     if (n_germplasm > 8192) {
       // beyond one workgroup's LDS: the shuffle rounds as radix sorts in HBM, envs side by side (sort_kernels.h)
       if (n_germplasm > 0x3FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_founders_device: germplasm of 2^30 rows and more");
-      const int rounds = shuffle_rounds_for(n_germplasm);
       for (int64_t e0 = 0; e0 < n_envs;) {
-        const int64_t segs = std::min(sort_batch(n_envs, n_germplasm), n_envs - e0);
-        SortBufs b{};
-        if (int rc = sort_layout(c, segs, n_germplasm, rounds, &b)) return rc;
         const uint2 *perm = nullptr;
-        if (int rc = shuffle_segments(c, env_key, e_total, e_off + e0, segs, n_germplasm, rounds, n, b, &perm)) return rc;
+        int64_t stride = 0, segs = 0;
+        if (int rc = shuffle_front(c, env_key, e_total, e_off + e0, n_envs - e0, n_germplasm, n, &perm, &stride, &segs)) return rc;
         hipLaunchKernelGGL(bh::take_front_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)segs), dim3(256), 0,
-                           c->stream, perm, b.stride, (int32_t)n, d_out + e0 * n);
+                           c->stream, perm, stride, (int32_t)n, d_out + e0 * n);
         BH_HIP(hipGetLastError());
         e0 += segs;
       }

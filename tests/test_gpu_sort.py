@@ -1,5 +1,6 @@
-"""GPU: the draws and rankings that no longer fit one workgroup's LDS -- JAX's sort-based shuffle as radix sorts in
-HBM (csrc/sort_kernels.h) -- against the CPU oracle, bit-exact, through the C ABI: the founder draw of
+"""GPU: the draws and rankings that no longer fit one workgroup's LDS -- JAX's sort-based shuffle by the wanted-only
+route (csrc/shuffle_sparse.h: the wanted front propagated backwards through the rounds, nothing sorted) or, where
+nearly all of a long list is wanted, as radix sorts in HBM (csrc/sort_kernels.h) -- against the CPU oracle, bit-exact, through the C ABI: the founder draw of
 `VecBreedGym.reset` (breedgym/vector/vec_env.py:22-27) on large germplasm, `SelectionScores._convert_actions`
 (breedgym/vector/vec_wrappers.py:61-79) at the shapes BASELINE's configs[2] and configs[3] give it with the
 reference's default k = n // 10, and `lax.top_k` with more than 16384 winners."""
@@ -27,7 +28,8 @@ def tiny_engine(layout):
 
 @pytest.mark.parametrize("N,n,E", [(8193, 50, 2), (10000, 10000, 3), (16385, 4096, 2), (65536, 8192, 2),
                                      (65536, 65536, 1), (100001, 1000, 5), (1 << 20, 4096, 1),
-                                     ((1 << 20) + 3, 1000, 3)])  # the last two: only the front of the last round is sorted
+                                     ((1 << 20) + 3, 1000, 3), (262144, 262144, 1), (262145, 16384, 2),
+                                     (300000, 100000, 1), (400001, 400001, 1)])  # the last two: the radix sort (most of a long list)
 def test_founder_draw_large_germplasm(N, n, E, layout):
     eng = tiny_engine(layout)
     key0 = co.key_from_seed(1234)
@@ -53,6 +55,7 @@ def test_founder_draw_through_the_env_window(layout):
                                         (4, 2048, 204, 2048),      # configs[2] with the reference's default k
                                         (2, 9000, 40, 780),        # n beyond the LDS kernel, pairs inside it
                                         (2, 20000, 1000, 5000),    # top-k by radix select, 499,500 pairs
+                                        (2, 20000, 800, 20000),    # 319,600 pairs, 20,000 of them wanted: the radix sort
                                         (1, 65536, 6553, 8192)])   # configs[3]: 21.5 M pairs, three rounds
 def test_selection_actions_large(E, n, k, nc, layout, rng):
     eng = tiny_engine(layout)
