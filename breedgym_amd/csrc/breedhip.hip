@@ -183,9 +183,10 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
         int e2, s2;
         std::frexp(emax, &e2);        // emax = f * 2^e2, f in [0.5, 1)
         std::frexp(2.0 * esum, &s2);  // the largest |GEBV| any genotype can reach: dosage <= 2
-        // every fixed-point effect fits the digits (|.| < 2^46), and the int64 in which the digit sums
-        // are recombined holds any row: sum_m 2 |round(e_m 2^sft)| <= 2 esum 2^sft + M < 2^61 + 2^18
-        sft = std::min(46 - e2, 61 - s2);
+        // every fixed-point effect fits the digits (|.| < 2^46), and the 56-bit sum field of the cells in which
+        // the digit sums meet (gebv_bits.h, GebvOut: the top byte counts arrivals) holds any row:
+        // sum_m 2 |round(e_m 2^sft)| <= 2 esum 2^sft + M < 2^54 + 2^18 < 2^55
+        sft = std::min(46 - e2, 54 - s2);
       }
       shift[(size_t)t] = sft;
       scale[(size_t)t] = std::ldexp(1.0, -sft);
@@ -286,7 +287,6 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_dig16) (void)hipFree(c->d_dig16);
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->d_gsum) (void)hipFree(c->d_gsum);
-  if (c->d_arrived) (void)hipFree(c->d_arrived);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
   if (c->d_effsum) (void)hipFree(c->d_effsum);

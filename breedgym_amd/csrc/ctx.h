@@ -93,8 +93,8 @@ struct bh_ctx {
   int32_t n_chunks = 0;
   int32_t *d_partial = nullptr;  // gebv_mfma_kernel's int32 slabs
   int64_t partial_cap = 0;       // int32 words
-  void *d_gsum = nullptr, *d_arrived = nullptr;  // gebv_bits.h, GebvOut: 64-bit sums per (row, trait), arrivals per row group
-  int64_t gsum_cap = 0, arrived_cap = 0;         // bytes
+  void *d_gsum = nullptr;  // gebv_bits.h, GebvOut: the final cells, then one set of cells per slice group
+  int64_t gsum_cap = 0;    // bytes
   // top-k scratch
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};
@@ -116,6 +116,7 @@ struct bh_ctx {
   bool big_lds_set = false;
   bool select_lds_set = false;
   bool sparse_lds_set = false;
+  unsigned bits_lds_set = 0;  // gebv_bits_kernel instances whose dynamic LDS limit has been raised
   // device-side error word: host memory the kernels can write (a hand-off wait that ran out, row_kernels.h)
   uint32_t *h_err = nullptr, *d_err = nullptr;
 };

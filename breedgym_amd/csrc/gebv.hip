@@ -58,26 +58,31 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
 }
 
 // where gebv_bits_kernel / gebv_bytes_kernel leave their sums (gebv_bits.h, GebvOut): grown on demand, zero whenever
-// no launch is in flight (the last workgroup of every row group leaves it so)
-static int gebv_out(bh_ctx *c, int64_t rows, int64_t row_groups, int64_t t0, int64_t tn, float *d_gebv, bh::GebvOut *o) {
-  const int64_t sums = row_groups * 128 * bh::kGsumTraits * (int64_t)sizeof(unsigned long long);
-  const int64_t counters = row_groups * (int64_t)sizeof(uint32_t);
-  if (sums > c->gsum_cap) {
-    if (int rc = ensure_scratch(c, &c->d_gsum, &c->gsum_cap, sums)) return rc;
-    BH_HIP(hipMemsetAsync(c->d_gsum, 0, (size_t)sums, c->stream));
+// no launch is in flight (whoever completes a cell leaves it so)
+static int gebv_out(bh_ctx *c, int64_t rows, int64_t row_groups, int64_t group_rows, int64_t slices, int64_t t0, int64_t tn,
+                    float *d_gebv, bh::GebvOut *o) {
+  int64_t gsz = 1;
+  while (gsz * gsz < slices) ++gsz;  // ~sqrt(slices) slices per group
+  const int64_t n_groups = (slices + gsz - 1) / gsz;
+  if (gsz > 127 || n_groups > 127) return fail(BH_ERR_UNSUPPORTED, "GEBV pass: too many K slices for the arrival counts");
+  const int64_t cells = row_groups * group_rows * bh::kGsumTraits;
+  const int64_t need = (n_groups + 1) * cells * (int64_t)sizeof(unsigned long long);
+  if (need > c->gsum_cap) {
+    if (int rc = ensure_scratch(c, &c->d_gsum, &c->gsum_cap, need)) return rc;
+    BH_HIP(hipMemsetAsync(c->d_gsum, 0, (size_t)need, c->stream));
   }
-  if (counters > c->arrived_cap) {
-    if (int rc = ensure_scratch(c, &c->d_arrived, &c->arrived_cap, counters)) return rc;
-    BH_HIP(hipMemsetAsync(c->d_arrived, 0, (size_t)counters, c->stream));
-  }
-  o->gsum = static_cast<unsigned long long *>(c->d_gsum);
-  o->arrived = static_cast<uint32_t *>(c->d_arrived);
+  o->acc2 = static_cast<unsigned long long *>(c->d_gsum);
+  o->acc1 = o->acc2 + cells;
+  o->group_stride = cells;
   o->scale = c->d_scale + t0;
   o->gebv = d_gebv;
   o->n_rows = (int32_t)rows;
   o->T = (int32_t)tn;
   o->Tstride = (int32_t)c->T;
   o->t0 = (int32_t)t0;
+  o->slices = (int32_t)slices;
+  o->group_size = (int32_t)gsz;
+  o->n_groups = (int32_t)n_groups;
   return BH_OK;
 }
 
@@ -97,24 +102,31 @@ static int64_t k_slices(int64_t row_groups, int64_t n_mc, int64_t wgs) {
 
 // GEBV of bit-plane rows on the matrix cores (gebv_bits.h), all traits.  `d_idx` (or null) picks the
 // source row of every output row.
-constexpr int kGebvBitsWgs = 512;
+constexpr int kGebvBitsWgs = 256;  // workgroups of eight waves: one per CU (112 KB of LDS with two column tiles)
+constexpr int kGebvBitsWaves = 4;  // two workgroups of four waves per CU (each ends its superstages with a barrier of its own: 29.3 against 31.5 us at 2048 x 100k x 8, 46.9 against 50.5 at 8192 x 100k x 1 with eight-wave workgroups)
 // ... and the byte-row pass: as many workgroups as are resident at once (three per CU: 152 VGPRs, 53 KB of LDS), never
 // more -- a second round of a few workgroups costs a whole round's time (784 workgroups: 117 us, 640: 91 us at
 // 2048 x 100k x 8, profiles/r03_ab_gebv_bytes.txt)
 constexpr int kGebvBytesWgs = 768;  // workgroups the K slicing aims at
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
-  constexpr int F = 1;  // 32-row tiles per wave
-  const int64_t row_groups = (rows + 128 * F - 1) / (128 * F);
-  const int64_t slices = k_slices(row_groups, c->n_mc, kGebvBitsWgs + row_groups - 1);
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;
+    const int waves = kGebvBitsWaves;
+    const int64_t group_rows = bh::bits_rows(waves), row_groups = (rows + group_rows - 1) / group_rows;
+    const int64_t wgs = kGebvBitsWgs * (8 / waves);  // eight waves per CU
+    // as many slices as there are workgroup slots, in whole eights (slice s runs on XCD s % 8).  NOT "no more than keep the
+    // longest as short": with one round of workgroups, slices of equal length all reach their way out together and its
+    // atomics (the memory side adds ~1.3 TB/s whatever the addresses) arrive in one burst behind the last product; where
+    // most slices are a macro-chunk shorter than the longest, theirs are added while the longest still compute
+    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((wgs + row_groups - 1) / row_groups, c->n_mc));
+    if (slices >= 8) slices -= slices % 8;
     bh::GebvBitsParams p{};
     p.rows = reinterpret_cast<const uint8_t *>(d_rows);
     p.idx = d_idx;
     p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
-    if (int rc = gebv_out(c, rows, row_groups, t0, tn, d_gebv, &p.out)) return rc;
+    if (int rc = gebv_out(c, rows, row_groups, group_rows, slices, t0, tn, d_gebv, &p.out)) return rc;
     p.row_bytes = (int64_t)16 * c->nw;
     p.n_src = (int32_t)n_src;
     p.n_rows = (int32_t)rows;
@@ -122,11 +134,22 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
     p.row_groups = (int32_t)row_groups;
     p.slices = (int32_t)slices;
     const dim3 grid(bh::slice_grid(row_groups, slices));
-    if (nt == 1)
-      hipLaunchKernelGGL((bh::gebv_bits_kernel<1, F>), grid, dim3(256), 0, c->stream, p);
+    auto launch = [&](auto kernel, int lds) -> int {
+      const unsigned bit = 1u << (2 * (waves == 8) + (nt == 2));
+      if (!(c->bits_lds_set & bit)) {
+        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        c->bits_lds_set |= bit;
+      }
+      hipLaunchKernelGGL(kernel, grid, dim3(64 * waves), lds, c->stream, p);
+      BH_HIP(hipGetLastError());
+      return BH_OK;
+    };
+    int rc;
+    if (waves == 8)
+      rc = nt == 1 ? launch(bh::gebv_bits_kernel<1, 8>, bh::gebv_bits_lds<1, 8>()) : launch(bh::gebv_bits_kernel<2, 8>, bh::gebv_bits_lds<2, 8>());
     else
-      hipLaunchKernelGGL((bh::gebv_bits_kernel<2, F>), grid, dim3(256), 0, c->stream, p);
-    BH_HIP(hipGetLastError());
+      rc = nt == 1 ? launch(bh::gebv_bits_kernel<1, 4>, bh::gebv_bits_lds<1, 4>()) : launch(bh::gebv_bits_kernel<2, 4>, bh::gebv_bits_lds<2, 4>());
+    if (rc) return rc;
   }
   return BH_OK;
 }
@@ -149,7 +172,7 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
     bh::GebvBytesParams p{};
     p.rows = d_pop;
     p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
-    if (int rc = gebv_out(c, rows, row_groups, t0, tn, d_gebv, &p.out)) return rc;
+    if (int rc = gebv_out(c, rows, row_groups, 128, slices, t0, tn, d_gebv, &p.out)) return rc;
     p.pitch = c->pitch;
     p.n_rows = (int32_t)rows;
     p.nvec = c->nvec;

@@ -9,7 +9,7 @@
 // bit 0 of every byte), stores them as a 32 x 128-byte tile of planes (row stride 144: conflict-free 16-byte reads),
 // and the MFMA phase reads its 64 bytes per lane from there instead of from memory -- the rest (six int8 digit
 // GEMMs, digit operands staged once per workgroup, K cut into slices) is
-// gebv_bits_kernel's, and so is the way out (gebv_tile_out, gebv_group_done).  Rows are read once, nothing else of their size moves: HBM-bound at 2 M bytes per individual.
+// gebv_bits_kernel's, and so is the way out (gebv_tile_out).  Rows are read once, nothing else of their size moves: HBM-bound at 2 M bytes per individual.
 //
 // A chunk = 512 markers = 1 KB of a byte row = 128 bytes of planes.  The packing of chunk c+1 is spread over the
 // four MFMA steps of chunk c (eight rows per step), its loads are issued two steps ahead (16 KB in flight per wave).
@@ -33,6 +33,7 @@ struct GebvBytesParams {
 };
 
 constexpr int kPlaneStride = 144;  // bytes from one row's planes to the next in LDS
+static_assert(2 * 32 * kPlaneStride >= 32 * 64 * 4, "a wave's planes also hold its tile of digit sums (gebv_tile_out)");
 
 // bit 0 of the 16 bytes of a genotype vector -> the vector's bit-plane word (bit i = byte i).  A dot product of four
 // 0/1 bytes with (1, 2, 4, 8) IS their nibble: v_dot4_u32_u8, one full-rate instruction per dword, the second of a
@@ -167,9 +168,7 @@ __global__ __launch_bounds__(256) void gebv_bytes_kernel(const GebvBytesParams p
     }
   }
 
-  __shared__ int last_flag;
-  const unsigned long long seen = gebv_tile_out<NT>(acc, reinterpret_cast<int32_t *>(&planes[wave][0][0]), p.out, row0, lane);
-  gebv_group_done(p.out, seen, rg, p.slices, tid, &last_flag);
+  gebv_tile_out<NT>(acc, reinterpret_cast<int32_t *>(&planes[wave][0][0]), p.out, row0, slice, lane);
 }
 
 }  // namespace bh

@@ -77,7 +77,7 @@ def gebv_isa(tmp_path_factory):
 
 def test_gebv_passes_keep_their_loads_in_flight(gebv_isa):
     """The matrix-core GEBV passes read their rows ahead (csrc/gebv_bytes.h: two batches of eight loads; gebv_bits.h: a
-    macro-chunk and four stages of digit operands).  That only holds if no row load sits under a lane condition: such a
+    macro-chunk of rows and two superstages of digit operands by LDS-DMA).  That only holds if no row load sits under a lane condition: such a
     load becomes a branch, and behind branches the compiler waits for everything in flight (`vmcnt(0)`) -- measured:
     87 -> 83 us and 30.6 -> 27.2 us at 2048 x 100k x 8.  The ISA must show the loads unguarded and the waits counted."""
     seen = set()
@@ -89,11 +89,20 @@ def test_gebv_passes_keep_their_loads_in_flight(gebv_isa):
             m = re.search(r"s_cbranch_execz\s+(\.LBB\d+_\d+)", line)
             if not m or labels.get(m.group(1), -1) <= i:
                 continue
-            skipped = [body[k].strip() for k in range(i, labels[m.group(1)]) if "global_load_dwordx4" in body[k]]
+            skipped = [body[k].strip() for k in range(i, labels[m.group(1)])
+                       if "global_load_dwordx4" in body[k] or "global_load_lds" in body[k]]
             assert not skipped, f"{name}: line {i}: a lane-guarded branch skips row / operand loads: {skipped[:2]}"
         counted = [int(m.group(1)) for l in body if (m := re.search(r"vmcnt\((\d+)\)", l))]
         deepest = 16 if "gebv_bytes_kernel" in name else 8
         assert max(counted) >= deepest, f"{name}: no wait leaves {deepest} loads in flight: {sorted(set(counted))}"
+        if "gebv_bits_kernel" in name:
+            # rows and digit operands come by LDS-DMA with hand-counted waits (gebv_bits.h): between the first and the
+            # last DMA nothing may wait for everything, and a superstage is entered by one barrier
+            dma = [i for i, l in enumerate(body) if "global_load_lds_dwordx4" in l]
+            assert len(dma) >= 20, f"{name}: the LDS-DMA stream is missing"
+            inside = [l.strip() for l in body[dma[0]:dma[-1]] if re.search(r"vmcnt\(0\)", l)]
+            assert not inside, f"{name}: a wait for every DMA inside the stream: {inside[:2]}"
+            assert sum("s_barrier" in l for l in body[dma[0]:dma[-1]]) == 2, name  # the loop body: an even and an odd superstage
         # every addition of a tile is issued before any is waited for: no atomic behind a lane-guarded branch either
         atomics = [i for i, l in enumerate(body) if "global_atomic_add_x2" in l]
         assert atomics and all("sc0" in body[i] for i in atomics), f"{name}: the additions must be returned atomics"
