@@ -281,12 +281,22 @@ def live_traffic(timeout=90):
         for k, (f, nf) in per["FETCH_SIZE"].items():
             w = per["WRITE_SIZE"].get(k, (0.0, 0))[0]
             name = k.split("(")[0].replace("void ", "").replace("bh::", "").replace(" ", "")
-            _LIVE_TRAFFIC[name] = ((2.0 * f + w) * 1024.0, nf)
+            _LIVE_TRAFFIC[name] = ((fetch_factor(name) * f + w) * 1024.0, nf)
         _LIVE_NOTE = "ok"
     except Exception as e:  # a missing counter, a timeout: the committed passes remain
         _LIVE_NOTE = f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def fetch_factor(kernel_name):
+    """What FETCH_SIZE has to be multiplied by.  The guide's gfx950 correction (x 2) is for wide coalesced streaming
+    reads, which the counter tallies at half their bytes.  gebv_bits_kernel's row reads are not of that shape -- eight
+    lanes take the eight 16-byte pieces of a 128-byte line in a permuted order (LDS-DMA, csrc/gebv_bits.h) -- and are
+    tallied in full: with the digit-operand DMAs removed the counter reads 59.6 MB per launch for 51.2 MB of rows,
+    with the row DMAs removed 3.9 MB for 6.4 MB of operands (profiles/r04_ab_gebv.txt, section 5).  So for that kernel
+    the counter is taken as it is (the operands' other half, 4 MB at 2048 x 100k x 8, is left out: -5 %)."""
+    return 1.0 if "gebv_bits_kernel" in kernel_name else 2.0
 
 
 def committed_traffic(kernel_prefix):
@@ -298,7 +308,7 @@ def committed_traffic(kernel_prefix):
         if name.startswith(want):
             return b, (f"measured by this run: child passes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
                        f"(separate), mean of {n} launches of {name}, 2 x FETCH_SIZE + WRITE_SIZE in KiB")
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         f = ROOT / "profiles" / name
         if not f.exists():
             continue
@@ -349,7 +359,7 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
                         if obs == "eager" and committed_traffic("packed_long_kernel")[0] else None,
              "traffic_source": committed_traffic("packed_long_kernel")[1] if obs == "eager" else None,
              "gebv_pass_ms": kms_all - kms,
-             "gebv_pass_note": "gebv_bits_kernel over the bit-plane offspring (0.2 GB); its last workgroups write the GEBVs",
+             "gebv_pass_note": "gebv_bits_kernel<1,4> over the bit-plane offspring (0.2 GB); whoever completes a cell writes its GEBV",
              "step_frac_of_hbm_peak": (nbytes + E * n * packed_pitch(M)) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
         if name == "eager":
             out.update(r)
@@ -382,12 +392,13 @@ def bench_c5(reps):
                       "roofline": roofline_of("gebv_bytes_kernel<2> (bh_gebv, byte-layout rows in one pass: bit planes built in LDS, digit GEMMs on the matrix cores, 64-bit sums by atomics)", N * 2 * M + eff_bytes, ms_bytes,
                                               traffic=committed_traffic("gebv_bytes_kernel<2")[0], traffic_source=committed_traffic("gebv_bytes_kernel<2")[1])},
         "bit_planes": {"ms": ms_bits, "individuals_per_s": N / (ms_bits * 1e-3),
-                       "roofline": roofline_of("gebv_bits_kernel<2,1> (bh_gather_packed, bit-plane rows)",
+                       "roofline": roofline_of("gebv_bits_kernel<2,4> (bh_gather_packed, bit-plane rows: rows and digit operands by LDS-DMA, two row tiles per operand read)",
                                                N * packed_pitch(M) + eff_bytes, ms_bits,
                                                traffic=committed_traffic("gebv_bits_kernel<2")[0],
                                                traffic_source=committed_traffic("gebv_bits_kernel<2")[1],
-                                               note="51 MB of rows: not bound by its bytes but by instruction issue -- operand build, LDS "
-                                                    "reads of the digit operands and MFMAs of two waves per SIMD (DESIGN 4d)",
+                                               note="51 MB of rows: not bound by its bytes.  Ramp, first operands and the way out of the K slices "
+                                                    "are ~14 of its ~29 us; the stream between runs at ~55 % of the matrix cores' rate with VALU "
+                                                    "(bits -> int8 operands), LDS and MFMA each busy more than half of it (profiles/r04_ab_gebv.txt)",
                                                mfma_int8_Tops=2.0 * N * M * 64 / (ms_bits * 1e-3) / 1e12, mfma_int8_peak_Tops=5000.0),
                        "api_level_GBps": N * 2 * M / (ms_bits * 1e-3) / 1e9},
     }
@@ -488,8 +499,9 @@ def bench_c4_one_rank(steps, warmup, barrier):
     key = np.array([0, 9], np.uint32)
     ms = time_events(lambda i: eng.selection_actions(scores, k, nc, key), max(5, steps // 4), warm=2)
     out["selection_actions"] = {"shape": f"n = {n}, k = {k} (n // 10), {k * (k - 1) // 2} pairs, n_crosses = {nc}", "ms": ms,
-                                "note": "bh_selection_actions: top-k through the radix sort, 3 shuffle rounds x 4 radix passes over "
-                                        "(key, value) pairs in HBM (the last round: its front only), un-ranking"}
+                                "note": "bh_selection_actions: top-k through the radix sort, then the wanted-only shuffle (the 8,192 wanted "
+                                        "positions propagated backwards through JAX's 3 rounds: per round two Threefry sweeps over the "
+                                        "21.5 M positions, nothing sorted; csrc/shuffle_sparse.h), un-ranking"}
     return out
 
 

@@ -295,6 +295,12 @@ __global__ __launch_bounds__(64 * WAVES) void gebv_bits_kernel(const GebvBitsPar
   const int ss_begin = slice_begin(slice, p.slices, 2 * p.n_mc), ss_end = slice_begin(slice + 1, p.slices, 2 * p.n_mc);
   const int mc_begin = ss_begin >> 1, mc_end = (ss_end + 1) >> 1;
   const int n_mc = mc_end - mc_begin;  // macro-chunks this slice touches, > 0 by construction of the grid (slices <= n_mc)
+  // The row groups of a slice run side by side on one XCD and want the same digit operands: started on the same
+  // macro-chunk they ask for every line of them at the same moment, and each request goes out to the fabric (PMC: 130 MB
+  // per launch at 2048 x 100k x 8 where rows and operands are 58).  A sum does not care for order: row group rg walks
+  // its slice from macro-chunk rg on, round the end -- one workgroup brings a line into the L2, the others find it there.
+  const int rot = rg % n_mc;
+  auto mc_of = [&](int m) { return mc_begin + (m + rot) % n_mc; };  // the m-th macro-chunk of this workgroup's walk (any m >= 0)
 
   uint8_t *rowslot = bits_lds + wave * (kBitsRowSlot * SLOTS);    // wave-uniform; slot s at + s kBitsRowSlot
   uint8_t *ring = bits_lds + WAVES * kBitsRowSlot * SLOTS;  // workgroup-uniform
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES) void gebv_bits_kernel(const GebvBitsPar
   };
   auto dma_b = [&](int k, int ring_slot) {  // this wave's share of superstage k of the slice -> that ring slot (NB instructions)
     // [mc][q 4][ntile 2][j 4][lane 64] x 16 bytes: a superstage = q 2 kk, 2 kk + 1 of one macro-chunk = 16 KB in a row
-    const i32x4 *src = p.B + ((int64_t)mc_begin * 4 + 2 * k) * 2 * 256;
+    const i32x4 *src = p.B + ((int64_t)mc_of(k >> 1) * 4 + 2 * (k & 1)) * 2 * 256;
     const uint32_t dst = ring_lds + ring_slot * (8192 * NT);
     if constexpr (NT == 2) {
 #pragma unroll
@@ -396,9 +402,9 @@ __global__ __launch_bounds__(64 * WAVES) void gebv_bits_kernel(const GebvBitsPar
   int slot_i = 0;  // ring slot of the superstage about to be computed
   auto next_slot = [&](int s, int by) { return (s + by) % RS; };
   // the prologue issues what the macro-chunks "before the first" would have: rows(0 .. A) and B(0), B(1) in that order
-  if constexpr (A == 1) dma_rows(mc_begin, 0);
+  if constexpr (A == 1) dma_rows(mc_of(0), 0);
   dma_b(0, 0);
-  dma_rows(mc_begin + A, A);
+  dma_rows(mc_of(A), A);
   dma_b(1, 1);
   __builtin_amdgcn_s_waitcnt(bits_vmcnt(A ? 2 * NB + RD : NB));  // rows(0) are in their slot
   BH_COMPILER_FENCE();
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(64 * WAVES) void gebv_bits_kernel(const GebvBitsPar
     __builtin_amdgcn_s_barrier();                // everybody's share of B(2 m) is in; everybody is done with the slot before
     BH_COMPILER_FENCE();
     dma_b(2 * m + 2, next_slot(slot_i, 2));
-    dma_rows(mc_begin + m + 1 + A, (m + 1 + A) % SLOTS);  // that row slot is free: macro-chunk m is in registers
-    if (const int ss = 2 * (mc_begin + m); ss >= ss_begin && ss < ss_end) {
+    dma_rows(mc_of(m + 1 + A), (m + 1 + A) % SLOTS);  // that row slot is free: macro-chunk m is in registers
+    if (const int ss = 2 * mc_of(m); ss >= ss_begin && ss < ss_end) {
       read_b(slot_i, 0, bA);
       read_b(slot_i, 1, bB);
       products(g, std::integral_constant<int, 0>{}, bA);
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES) void gebv_bits_kernel(const GebvBitsPar
     __builtin_amdgcn_s_barrier();
     BH_COMPILER_FENCE();
     dma_b(2 * m + 3, next_slot(slot_i, 2));
-    const int ss_odd = 2 * (mc_begin + m) + 1;
+    const int ss_odd = 2 * mc_of(m) + 1;
     const bool odd_in = ss_odd >= ss_begin && ss_odd < ss_end;
     if (odd_in) {
       read_b(slot_i, 0, bA);

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 R=$(pwd)
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
