@@ -96,6 +96,7 @@ SIGNATURES = {
     "bh_destroy": (_int, [_vp]),
     "bh_set_stream": (_int, [_vp, _vp]),
     "bh_sync": (_int, [_vp]),
+    "bh_release_scratch": (_int, [_vp]),
     "bh_row_pitch": (_i64, [_vp]),
     "bh_n_markers": (_i64, [_vp]),
     "bh_n_traits": (_i64, [_vp]),

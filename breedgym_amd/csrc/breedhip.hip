@@ -318,6 +318,33 @@ int bh_sync(bh_ctx *c) {
   return check_ctx(c);  // ... and whatever the launches that just finished had to report
 }
 
+int bh_release_scratch(bh_ctx *c) {
+  if (int rc = check_ctx(c)) return rc;
+  if (int rc = flush_founders(c)) return rc;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  auto drop = [](void *&p, int64_t &cap) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  };
+  drop(c->d_sort, c->sort_cap);
+  drop(c->d_best, c->best_cap);
+  drop(c->d_gsum, c->gsum_cap);  // (zero whenever no launch is in flight: nothing is lost)
+  {
+    void *p = c->d_partial;
+    drop(p, c->partial_cap);
+    c->d_partial = nullptr;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (c->d_cand_s[i]) (void)hipFree(c->d_cand_s[i]);
+    if (c->d_cand_i[i]) (void)hipFree(c->d_cand_i[i]);
+    c->d_cand_s[i] = nullptr;
+    c->d_cand_i[i] = nullptr;
+  }
+  c->cand_cap = 0;
+  return BH_OK;
+}
+
 int64_t bh_row_pitch(const bh_ctx *c) { return c ? c->pitch : 0; }
 int64_t bh_n_markers(const bh_ctx *c) { return c ? c->M : 0; }
 int64_t bh_n_traits(const bh_ctx *c) { return c ? c->T : 0; }

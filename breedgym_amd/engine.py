@@ -667,3 +667,7 @@ class HipEngine(EngineBase):
 
     def sync(self) -> None:
         _lib.check(self._L.bh_sync(self._h))
+
+    def release_scratch(self) -> None:
+        """Give back the scratch the context has grown for its larger calls (bh_release_scratch)."""
+        _lib.check(self._L.bh_release_scratch(self._h))

@@ -82,6 +82,11 @@ int bh_destroy(bh_ctx *ctx);
  * caller's race, not the library's. */
 int bh_set_stream(bh_ctx *ctx, void *hip_stream);
 int bh_sync(bh_ctx *ctx);
+/* Frees the scratch buffers a context has grown for its larger calls (the draws' and top-k's sort scratch, candidate
+ * lists, the GEBV passes' cells and slabs); they are allocated again on demand.  Waits for the stream first.  The
+ * reference has nothing to replace here (JAX's allocator owns its temporaries); a long-lived process that made one
+ * 65,536-individual selection and goes back to small envs gets its ~0.5-1 GB back with this. */
+int bh_release_scratch(bh_ctx *ctx);
 int64_t bh_row_pitch(const bh_ctx *ctx);
 int64_t bh_n_markers(const bh_ctx *ctx);
 int64_t bh_n_traits(const bh_ctx *ctx);
@@ -170,7 +175,8 @@ int bh_topk(bh_ctx *ctx, const float *d_scores, int64_t n_rows, int64_t n, int64
  * n.  d_scores (E, n) f32 -> d_actions (E, n, 2) int32; env_key is advanced like the wrapper's
  * `random_key` (keys[0]).  Up to n <= 8192 and k(k-1)/2 <= 8192 one workgroup per env does it all in LDS; beyond
  * (the reference's default k = n // 10 at 2048 individuals already is: 20,706 pairs; 65,536 individuals give
- * 21.5 M pairs and three shuffle rounds) the pair ranks are shuffled by radix sorts in HBM.  k(k-1)/2 < 2^30. */
+ * 21.5 M pairs and three shuffle rounds) only the n_crosses wanted positions are followed backwards through the
+ * shuffle rounds (bh_founders_device has the routes).  Asynchronous like every launch.  k(k-1)/2 < 2^30. */
 int bh_selection_actions(bh_ctx *ctx, const float *d_scores, int64_t n_envs, int64_t n, int64_t k,
                          int64_t n_crosses, uint32_t env_key[2], int32_t *d_actions);
 
@@ -298,7 +304,11 @@ int bh_founders(uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm, int64_
 
 /* The same draw made on the device, written to d_out (E, n) int32 in stream order; env_key is advanced on the
  * host.  Germplasm up to 8192 rows: one workgroup per env, Threefry + bitonic sort in LDS; larger (below 2^30
- * rows): the shuffle rounds as stable radix sorts in HBM, envs side by side -- nothing goes through the host. */
+ * rows): only the n wanted positions are followed backwards through JAX's shuffle rounds (two Threefry sweeps per
+ * round, nothing sorted), or -- when most of a germplasm of more than 2^18 rows is wanted -- the rounds as stable
+ * radix sorts in HBM; envs side by side.  Asynchronous: nothing goes through the host, nothing is waited for.  The
+ * scratch of these routes (up to ~1 GB for 2^25 rows; bh_selection_actions shares it) stays with the context until
+ * bh_release_scratch. */
 int bh_founders_device(bh_ctx *ctx, uint32_t env_key[2], int64_t n_envs, int64_t n_germplasm,
                        int64_t n, int32_t *d_out);
 

@@ -306,7 +306,7 @@ def _pair_actions_restated(scores, n):
         ex = np.exp(v - v.max())
         sm = ex / ex.sum(dtype=np.float64).astype(np.float32)
         rep = np.ceil(sm * np.float32(n)).astype(np.int64)
-        pairs = np.stack((best // scores.shape[-1], best % scores.shape[-1]), 1)
+        pairs = np.stack((best // n, best % n), 1)  # (flat index // n, flat index % n), vec_wrappers.py:104-105
         out[e] = np.repeat(pairs, rep, axis=0)[:n]
     return out
 
@@ -782,3 +782,19 @@ def test_pair_actions_kernel(E, n, rng):
         scores[:, 1, 2] = scores[:, 0, 1] = scores.max() + 1.0  # two pairs tie for the best score
     got = eng.pair_actions(torch.from_numpy(scores), n).cpu().numpy()
     assert np.array_equal(got, _pair_actions_restated(scores, n))
+
+
+def test_pair_actions_of_a_multi_trait_outer_sum(rng):
+    """What the reference's own PairScores test feeds with a 7-trait map (tests/test_vec.py:196-200:
+    np.add.outer of (E, n, T) GEBVs -> (E, n, T, E, n, T)): `_convert_actions` flattens an env's block whatever its
+    shape (vec_wrappers.py:102) and the pairs are (flat // n, flat % n), beyond n - 1 and all.  bh_pair_actions takes
+    the row length; the env then clamps the indices like JAX's gather."""
+    from breedgym_amd import HipEngine
+
+    E, n, T = 2, 24, 3
+    eng = HipEngine(np.full(8, 0.1, np.float32), np.ones((8, 1), np.float32))
+    g = rng.standard_normal((E, n, T)).astype(np.float32)
+    scores = np.add.outer(g, g)  # (E, n, T, E, n, T)
+    got = eng.pair_actions(torch.from_numpy(scores), n).cpu().numpy()
+    ref = _pair_actions_restated(scores.reshape(E, -1), n)
+    assert np.array_equal(got, ref) and ref.max() >= n  # indices beyond the generation do occur

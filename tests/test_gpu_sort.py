@@ -119,3 +119,19 @@ def test_selection_scores_env_with_reference_defaults_at_c3():
         _, _, _, _, infos = env.env.step(low)
     obs, rew, ter, tru, infos = env.step(infos["GEBV"][..., 0])  # ... and whole: the horizon step
     assert tru.all() and obs.shape == (E, n, M, 2)
+
+
+def test_release_scratch_then_draw_again(layout):
+    """bh_release_scratch gives the sort scratch back; the next large draw allocates it again and is the same draw."""
+    eng = tiny_engine(layout)
+    key0 = co.key_from_seed(77)
+    a, _ = eng.founders(key0, 2, 70000, 3000)
+    eng.release_scratch()
+    b, _ = eng.founders(key0, 2, 70000, 3000)
+    ref, _ = co.founders(key0, 2, 70000, 3000)
+    assert np.array_equal(a.cpu().numpy().reshape(2, 3000), ref) and np.array_equal(b.cpu().numpy().reshape(2, 3000), ref)
+    s = np.random.default_rng(1).standard_normal((2, 9000)).astype(np.float32)
+    got, _ = eng.selection_actions(torch.from_numpy(s), 300, 2000, key0)
+    eng.release_scratch()
+    ref_a, _ = co.selection_actions(s, 300, 2000, key0)
+    assert np.array_equal(got.cpu().numpy(), ref_a)
