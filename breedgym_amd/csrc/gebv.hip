@@ -113,15 +113,19 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;
+    // one column tile (<= 5 traits): the LDS-DMA pass; two: round 3's register-staged pass (gebv_bits.h says why)
+    const bool regs = nt == 2;
     const int waves = kGebvBitsWaves;
-    const int64_t group_rows = bh::bits_rows(waves), row_groups = (rows + group_rows - 1) / group_rows;
-    const int64_t wgs = kGebvBitsWgs * (8 / waves);  // eight waves per CU
-    // as many slices as there are workgroup slots, in whole eights (slice s runs on XCD s % 8).  NOT "no more than keep the
-    // longest as short": with one round of workgroups, slices of equal length all reach their way out together and its
-    // atomics (the memory side adds ~1.3 TB/s whatever the addresses) arrive in one burst behind the last product; where
-    // most slices are a macro-chunk shorter than the longest, theirs are added while the longest still compute
-    int64_t slices = std::max<int64_t>(1, std::min<int64_t>((wgs + row_groups - 1) / row_groups, c->n_mc));
-    if (slices >= 8) slices -= slices % 8;
+    const int64_t group_rows = regs ? 128 : bh::bits_rows(waves), row_groups = (rows + group_rows - 1) / group_rows;
+    const int64_t wgs = regs ? 512 : kGebvBitsWgs * (8 / waves);  // eight waves per CU
+    // as many slices as there are workgroup slots, in whole eights (slice s runs on XCD s % 8)
+    int64_t slices;
+    if (regs) {
+      slices = k_slices(row_groups, c->n_mc, wgs + row_groups - 1);
+    } else {
+      slices = std::max<int64_t>(1, std::min<int64_t>((wgs + row_groups - 1) / row_groups, c->n_mc));
+      if (slices >= 8) slices -= slices % 8;
+    }
     bh::GebvBitsParams p{};
     p.rows = reinterpret_cast<const uint8_t *>(d_rows);
     p.idx = d_idx;
@@ -134,21 +138,19 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
     p.row_groups = (int32_t)row_groups;
     p.slices = (int32_t)slices;
     const dim3 grid(bh::slice_grid(row_groups, slices));
-    auto launch = [&](auto kernel, int lds) -> int {
-      const unsigned bit = 1u << (2 * (waves == 8) + (nt == 2));
-      if (!(c->bits_lds_set & bit)) {
-        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        c->bits_lds_set |= bit;
+    if (regs) {
+      hipLaunchKernelGGL(bh::gebv_bits_regs_kernel<2>, grid, dim3(256), 0, c->stream, p);
+    } else {
+      constexpr int lds = bh::gebv_bits_lds<1, kGebvBitsWaves>();
+      if (!c->bits_lds_set) {
+        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bh::gebv_bits_kernel<1, kGebvBitsWaves>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        c->bits_lds_set = 1;
       }
-      hipLaunchKernelGGL(kernel, grid, dim3(64 * waves), lds, c->stream, p);
-      BH_HIP(hipGetLastError());
-      return BH_OK;
-    };
-    int rc;
-    if (waves == 8)
-      rc = nt == 1 ? launch(bh::gebv_bits_kernel<1, 8>, bh::gebv_bits_lds<1, 8>()) : launch(bh::gebv_bits_kernel<2, 8>, bh::gebv_bits_lds<2, 8>());
-    else
-      rc = nt == 1 ? launch(bh::gebv_bits_kernel<1, 4>, bh::gebv_bits_lds<1, 4>()) : launch(bh::gebv_bits_kernel<2, 4>, bh::gebv_bits_lds<2, 4>());
+      hipLaunchKernelGGL((bh::gebv_bits_kernel<1, kGebvBitsWaves>), grid, dim3(64 * waves), lds, c->stream, p);
+    }
+    BH_HIP(hipGetLastError());
+    const int rc = BH_OK;
     if (rc) return rc;
   }
   return BH_OK;

@@ -461,4 +461,158 @@ __global__ __launch_bounds__(64 * WAVES) void gebv_bits_kernel(const GebvBitsPar
   gebv_tiles_out<NT, F>(acc, reinterpret_cast<int32_t *>(rowslot), p.out, row0, slice, lane);
 }
 
+// ---- the pass as round 3 had it, with round 4's way out: kept for packs of more than five traits --------------------
+// Four waves x one 32-row tile (128 rows per workgroup, two workgroups per CU), rows through registers and a turn in
+// LDS, the digit operands of a stage through registers into two LDS buffers, a barrier per 128 markers.  The rebuild
+// above moves less through LDS per product and needs no registers for staging, and for one column tile (a pass bound by
+// its rows) it is the faster one (46.9 against 50.3 us at 8192 x 100k x 1); with two column tiles its longer superstages
+// pay more per barrier and the two forms come out 29.3-31.7 against 26-28 us at 2048 x 100k x 8
+// (profiles/r04_ab_gebv.txt, section 6) -- so this one serves them.
+
+template <int NT>
+__global__ __launch_bounds__(256) void gebv_bits_regs_kernel(const GebvBitsParams p) {
+  constexpr int F = 1;
+  static_assert(NT == 1 || NT == 2, "one or two 32-column tiles");
+  // a stage = the digit operands of QS steps (8 KB): with one column tile a step is only four MFMAs per tile,
+  // too little between two barriers
+  constexpr int QS = NT == 1 ? 2 : 1;
+  constexpr int STAGE_V = NT * QS * 256;  // i32x4 per stage in LDS
+  __shared__ i32x4 ldsB[2][STAGE_V];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int rg, slice;
+  if (!slice_of_block(p.row_groups, p.slices, rg, slice)) return;  // uniform per workgroup
+  const int mc_begin = slice_begin(slice, p.slices, p.n_mc), mc_end = slice_begin(slice + 1, p.slices, p.n_mc);
+  const int n_stages = (mc_end - mc_begin) * (4 / QS);  // > 0 by construction of the grid
+
+  // every wave takes part in the staging and the barriers, also one whose tiles lie past the last row
+  // (its lanes re-read the last row; gebv_tile_out adds nothing of it)
+  //
+  // How the rows are read.  The MFMA wants lane (r, h) to hold 64 bytes of row r per macro-chunk; read that way
+  // (round 2) an instruction touches 32 rows and takes a quarter of a 128-byte line from each: four requests per
+  // line at the L2.  Now an instruction takes WHOLE lines (8192 x 100k x 1: 61 -> 56 us, 2048 x 100k x 8: 31.6 -> 30.6):
+  // lane l reads piece l & 7 of row 8 i + (l >> 3), i = 0..3, and the tile of 32 x 128 bytes is turned in LDS (row
+  // stride 144: conflict-free 16-byte reads) -- written and read back by the same wave, no barrier.
+  constexpr int kPlaneStrideBits = 144;  // bytes from one row's 128 bytes of planes to the next in LDS
+  // (a wave's tile of planes is also where its digit sums are turned on the way out: 32 x 64 int32)
+  __shared__ __attribute__((aligned(16))) uint8_t turn[4][32 * 64 * 4];
+  static_assert(32 * 64 * 4 >= 32 * kPlaneStrideBits, "the way out's tile holds the planes too");
+  const int tile0 = rg * 4 + wave;
+  const uint8_t *pa[4];  // the four rows this lane reads a piece of
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = min(tile0 * 32 + 8 * i + (lane >> 3), p.n_rows - 1);
+    if (p.idx) {
+      int s = p.idx[row];
+      if (s < 0) s += p.n_src;
+      row = s < 0 ? 0 : (s >= p.n_src ? p.n_src - 1 : s);
+    }
+    pa[i] = p.rows + (int64_t)row * p.row_bytes;  // the row's start: the piece offset is added per load (load_chunk)
+  }
+
+  i32x16 acc[F][NT];
+#pragma unroll
+  for (int f = 0; f < F; ++f)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[f][j][k] = 0;
+
+  struct Chunk {
+    uint4 g[F][4];
+    uint32_t keep;  // all ones where this lane's pieces exist
+  };
+  auto load_chunk = [&](int mc, Chunk &c) {  // whole lines: c.g[0][i] = piece (lane & 7) of row 8 i + (lane >> 3)
+    // a 16-byte piece is wholly inside the row or wholly beyond it (row_bytes % 16 == 0)
+    // every lane loads -- one with nothing to read takes its row's first piece and zeroes it: a load under a lane
+    // condition becomes a branch, and behind branches the compiler waits for every load in flight (gebv_bytes.h)
+    // (the zeroing waits for turn_chunk: here it would wait for the loads)
+    const bool in = mc < mc_end && (int64_t)mc * 128 + 16 * (lane & 7) + 16 <= p.row_bytes;
+    // (an idle lane takes the row's FIRST piece, whatever the lane: with the lane's own piece offset in the base a
+    // row of fewer than eight pieces -- M <= 448 -- would be read past its end)
+    const int64_t off = in ? (int64_t)mc * 128 + 16 * (lane & 7) : 0;
+    c.keep = in ? ~0u : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.g[0][i] = *reinterpret_cast<const uint4 *>(pa[i] + off);
+  };
+  auto turn_chunk = [&](Chunk &c) {  // ... -> c.g[0][q] = bytes [64 h + 16 q, +16) of row r: what the MFMA phase reads
+    uint8_t *t = &turn[wave][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint4 v = c.g[0][i];
+      *reinterpret_cast<uint4 *>(t + (8 * i + (lane >> 3)) * kPlaneStrideBits + 16 * (lane & 7)) =
+          make_uint4(v.x & c.keep, v.y & c.keep, v.z & c.keep, v.w & c.keep);
+    }
+    // (a wave's LDS operations are served in order: its reads below see its writes above)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.g[0][q] = *reinterpret_cast<const uint4 *>(t + r * kPlaneStrideBits + 64 * h + 16 * q);
+  };
+  // digit operands of stage k of this slice -> registers (NT * QS 16-byte pieces per thread), kRing stages ahead of
+  // the stage that reads them from LDS: a stage is eight MFMAs long, an L2 hit under load ten times that -- asked
+  // for two stages ahead (round 2) the pass ran at the pace of its operand loads.  Stage s lives in register set
+  // s % kRing; the sets are named by constants (the loop body below is kRing stages or a multiple).
+  constexpr int kRing = 4;
+  i32x4 breg[kRing][NT * QS];
+  auto load_b = [&](int k, auto set) {
+    const int kk = min(k, n_stages - 1);  // past the slice: its last stage again, never used (no branch: load_chunk)
+    const i32x4 *src = p.B + ((int64_t)(mc_begin * 4 + kk * QS) * 2) * 256;
+#pragma unroll
+    for (int u = 0; u < QS; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) breg[decltype(set)::value][u * NT + t] = src[(u * 2 + t) * 256 + tid];
+  };
+  auto store_b = [&](int buf, auto set) {
+#pragma unroll
+    for (int u = 0; u < NT * QS; ++u) ldsB[buf][u * 256 + tid] = breg[decltype(set)::value][u];
+  };
+  auto step = [&](int buf, int u, const Chunk &c, int q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      i32x4 b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = ldsB[buf][(u * NT + t) * 256 + j * 64 + lane];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const uint4 g = c.g[f][q];
+        const uint32_t x = j == 0 ? g.x : j == 1 ? g.y : j == 2 ? g.z : g.w;
+        const i32x4 a = dosage16_from_bits(x);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[f][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[t], acc[f][t], 0, 0, 0);
+      }
+    }
+  };
+  constexpr int kChunkStages = 4 / QS;
+  static_assert((2 * kChunkStages) % kRing == 0, "the loop body (two macro-chunks) is whole turns of the ring");
+  auto chunk_stages = [&](int &k, Chunk &c, auto first) {  // `first`: this chunk's first stage, modulo kRing
+    turn_chunk(c);
+    static_for<kChunkStages>([&](auto qq) {
+      const std::integral_constant<int, (decltype(first)::value + decltype(qq)::value + 1) % kRing> set;  // of stage k + 1
+      store_b((k + 1) & 1, set);  // its LDS buffer was last read in stage k-1, before the barrier
+      load_b(k + 1 + kRing, set);
+#pragma unroll
+      for (int u = 0; u < QS; ++u) step(k & 1, u, c, decltype(qq)::value * QS + u);
+      __syncthreads();
+      ++k;
+    });
+  };
+
+  Chunk c0, c1;
+  load_chunk(mc_begin, c0);
+  static_for<kRing>([&](auto s) { load_b(decltype(s)::value, s); });
+  store_b(0, std::integral_constant<int, 0>{});
+  load_b(kRing, std::integral_constant<int, 0>{});
+  __syncthreads();
+  int k = 0;
+  for (int mc = mc_begin; mc < mc_end; mc += 2) {
+    load_chunk(mc + 1, c1);
+    chunk_stages(k, c0, std::integral_constant<int, 0>{});
+    if (mc + 1 < mc_end) {
+      load_chunk(mc + 2, c0);
+      chunk_stages(k, c1, std::integral_constant<int, kChunkStages % kRing>{});
+    }
+  }
+
+  gebv_tile_out<NT>(acc[0], reinterpret_cast<int32_t *>(&turn[wave][0]), p.out, tile0 * 32, slice, lane);
+}
+
 }  // namespace bh
