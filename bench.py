@@ -497,7 +497,7 @@ def bench_c4_one_rank(steps, warmup, barrier):
     n, k, nc = 65_536, 6_553, 8_192
     scores = torch.randn((1, n), device=eng.device)
     key = np.array([0, 9], np.uint32)
-    ms = time_events(lambda i: eng.selection_actions(scores, k, nc, key), max(5, steps // 4), warm=2)
+    ms = time_events(lambda i: eng.selection_actions(scores, k, nc, key), max(20, steps), warm=3)
     out["selection_actions"] = {"shape": f"n = {n}, k = {k} (n // 10), {k * (k - 1) // 2} pairs, n_crosses = {nc}", "ms": ms,
                                 "note": "bh_selection_actions: top-k through the radix sort, then the wanted-only shuffle (the 8,192 wanted "
                                         "positions propagated backwards through JAX's 3 rounds: per round two Threefry sweeps over the "
