@@ -193,8 +193,10 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
     }
     BH_HIP_C(hipMalloc(&c->d_scale, (size_t)n_traits * sizeof(double)));
     BH_HIP_C(hipMemcpy(c->d_scale, scale.data(), (size_t)n_traits * sizeof(double), hipMemcpyHostToDevice));
-    {  // the same fixed-point effects as three balanced base-65536 digits, 8 markers (one vector) per 16 bytes
-      std::vector<int16_t> dig((size_t)n_traits * c->nvec * 3 * 8, (int16_t)0);
+    {  // the same fixed-point effects as three balanced base-65536 digits, 8 markers (one vector) per 16 bytes; every
+      // plane ends with a zero block (index nvec): where the lanes that redo a row's last vector point their loads
+      const int64_t nvd = (int64_t)c->nvec + 1;
+      std::vector<int16_t> dig((size_t)n_traits * nvd * 3 * 8, (int16_t)0);
       for (int64_t t = 0; t < n_traits; ++t)
         for (int64_t m = 0; m < n_markers; ++m) {
           long long fix = std::llround(std::ldexp((double)effects[m * n_traits + t], shift[(size_t)t]));
@@ -202,7 +204,7 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
             long long d = ((fix % 65536) + 65536) % 65536;
             if (d >= 32768) d -= 65536;
             fix = (fix - d) / 65536;
-            dig[(size_t)(((t * 3 + j) * c->nvec + (m >> 3)) * 8 + (m & 7))] = (int16_t)d;
+            dig[(size_t)(((t * 3 + j) * nvd + (m >> 3)) * 8 + (m & 7))] = (int16_t)d;
           }
         }
       BH_HIP_C(hipMalloc(&c->d_dig16, dig.size() * sizeof(int16_t)));

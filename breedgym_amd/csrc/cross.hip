@@ -265,8 +265,21 @@ int launch_prow_mode(const bh_ctx *c, const bh::PackedParams &p, int tt) {
 }
 
 // few crosses need masks (they are shared by all envs, or the batch is small): put four waves on
-// each so that the mask role is as short as the streaming beside it
-int mask_waves_for_runahead(const bh_ctx *c, int64_t B) { return (B * 4 <= 2048 || c->M > 16384) ? 4 : 1; }
+// each so that the mask role is as short as the streaming beside it.  "Few" is against the row work beside them: with
+// shared keys and eight envs or more there is at most one keyed cross per row workgroup (eight rows) however large the
+// batch -- 64 envs x 1024 took the one-wave form (and with it the plain f64 row loop) at 672 us; four-wave groups and
+// the pipelined stream: 2.0x less
+int mask_waves_for_runahead(const bh_ctx *c, int64_t B, int64_t rows) {
+  return (B * 4 <= 2048 || c->M > 16384 || B * 8 <= rows) ? 4 : 1;
+}
+
+// How the pipelined stream stores the byte observation (PackedParams::obs_nt), measured at 10k markers
+// (tools/time_stream_obs.py, profiles/r04_ab_obs_stores.txt): while two alternating observation blocks and the state
+// fit the 256 MB Infinity Cache, write-through stores (sc1: the line leaves the XCD's L2 at once, nothing is left to
+// write back when the kernel ends) take 0.6 us off the launch and 0.4 off the gap behind it; beyond, write-through is
+// the slowest form (8192 rows: 67 us against 43) and non-temporal the fastest by far (16384 rows: 80 us against 140 for
+// plain stores, 32768: 163 against 280).
+int obs_store_nt(const bh_ctx *c, int64_t rows) { return rows * c->pitch > (int64_t)96 << 20; }
 
 // make d_Z[buf] hold at least `bytes`; growing it waits for everything that may still touch it
 int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
@@ -567,7 +580,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
         kwn = {0, Bn};
       }
     }
-    const bool long_stream = packed && (!c->prefetch || mask_waves_for_runahead(c, Bn) == 4) && long_row_turns(c, rows) > 1;
+    const bool long_stream = packed && (!c->prefetch || mask_waves_for_runahead(c, Bn, rows) == 4) && long_row_turns(c, rows) > 1;
     const bool mfma_after =
         d_gebv && (packed ? (c->T >= kMfmaGebvMinTraits ? use_bits_gebv(c, rows) : long_stream) : use_mfma_gebv(c, rows));
     // mutation flips alleles after the crossover: the GEBV (and the reward) must see the mutated rows, so they
@@ -584,7 +597,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     int mw = 1;
     if (run_ahead) {
       if (int rc = ensure_z(c, 1 - buf, Bn * 16 * c->nw)) return rc;
-      mw = mask_waves_for_runahead(c, Bn);
+      mw = mask_waves_for_runahead(c, Bn, rows);
       mp = mask_params(c, 1 - buf, nk.x, nk.y, Bn, mw, dhn, kwn);
     }
     const bool wide = rows >= 4096;  // else one row per wave: more waves in flight
@@ -602,6 +615,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.src = static_cast<const uint16_t *>(d_pool);
       p.outp = d_out_packed;
       p.outb = d_out_bytes;
+      p.obs_nt = obs_store_nt(c, rows);
       p.idx = d_idx;
       p.gebv = d_gebv;
       p.Z = c->d_Z[buf];
@@ -813,6 +827,7 @@ int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const i
   p.src = d_src;
   p.outp = d_out_packed;
   p.outb = d_out_bytes;
+  p.obs_nt = obs_store_nt(c, n_rows);
   p.idx = d_idx;
   p.gebv = d_gebv;
   p.n_pool = (int32_t)src_rows;

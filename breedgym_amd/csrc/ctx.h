@@ -89,7 +89,7 @@ struct bh_ctx {
   std::vector<void *> d_Bbits;  // the same digits in the operand order of gebv_bits_kernel
   int32_t n_mc = 0;                  // 512-marker macro-chunks per row
   double *d_scale = nullptr;  // (T) 2^-s_t
-  uint4 *d_dig16 = nullptr;   // (T, 3, nvec) int16 digit planes of the fixed-point effects (packed_kernels.h)
+  uint4 *d_dig16 = nullptr;   // (T, 3, nvec + 1) int16 digit planes, the last block of a plane zero, of the fixed-point effects (packed_kernels.h)
   int32_t n_chunks = 0;
   int32_t *d_partial = nullptr;  // gebv_mfma_kernel's int32 slabs
   int64_t partial_cap = 0;       // int32 words

@@ -63,6 +63,8 @@ struct PackedParams {
   float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
   int64_t reward_pitch;  // floats between the words of two envs in both (RowParams)
   int32_t n_envs;
+  int32_t obs_nt;  // how the pipelined stream stores the byte observation: 0 write-through (sc1), 1 non-temporal
+                   // (obs_store_policy in cross.hip)
   char *spare;  // 16 KB nobody reads: where the lanes past a row's end send their stores in the LDS-DMA stream
                 // (packed_dma.h), so that every trip issues the same number of memory operations
 };
@@ -85,6 +87,27 @@ __device__ __forceinline__ uint4 expand_vector(uint32_t o16) {
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 __device__ __forceinline__ uint32_t cross16(uint32_t p0, uint32_t p1, uint32_t z) {
   return bfi(0x5555u, bfi(z, p0 >> 1, p0), bfi(z, p1, p1 << 1)) & 0xffffu;
+}
+
+// The same word without the final `& 0xffff`: for users that only look at its low 16 bits.
+__device__ __forceinline__ uint32_t cross16_raw(uint32_t p0, uint32_t p1, uint32_t z) {
+  return bfi(0x5555u, bfi(z, p0 >> 1, p0), bfi(z, p1, p1 << 1));
+}
+
+// Two 16-entry tables in LDS, indexed by a nibble of an offspring word = two markers (bits a0 a1 of marker 2k, then of
+// marker 2k+1): [0..15] the nibble's four bytes of the byte layout (what expand_dword computes), [272..287] the two
+// markers' dosages as two int16 (what the in-stream GEBV feeds v_dot2_i32_i16).  A lookup is a ds_read_b32 whose lanes
+// either agree (broadcast) or hit different banks (16 entries on 16 banks): conflict-free whatever the genotypes, and
+// it replaces 6 vector-ALU instructions per nibble (bfe, mul, and; shift, add, and) with 2 (the entry's address) in a
+// launch whose stream runs at the pace of VALU issue.
+constexpr int kNibbleLutDosage = 272;  // dwords between the two tables: beyond a ds_read2_b32's reach (255), not a
+                                       // multiple of 64 (ds_read2st64): fused, the pair lands in two neighbouring
+                                       // registers and the four dwords of a vector have to be moved together again
+constexpr int kNibbleLutWords = kNibbleLutDosage + 16;
+__device__ __forceinline__ void nibble_lut_init(uint32_t *lut, int i) {  // threads 0..15, before a workgroup barrier
+  const uint32_t n = (uint32_t)i & 15u;
+  lut[n] = ((n * 0x00204081u) & 0x01010101u);
+  lut[kNibbleLutDosage + n] = ((n & 1u) + ((n >> 1) & 1u)) | ((((n >> 2) & 1u) + (n >> 3)) << 16);
 }
 
 // One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
@@ -222,9 +245,10 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 // gebv_bits.h).  p.seq row groups per wave, one after the other: that keeps the grid of a launch of many
 // long rows small enough to be resident at once (not a question of DRAM pages: stores run at the same rate for
 // 512 ... 8192 concurrent row streams, tools/store_streams.hip).
-template <int TT, int MODE, int R, bool OBS, int VPT = 1>
+template <int TT, int MODE, int R, bool OBS, int VPT = 1, bool LUT = false, bool OBSNT = false>
 __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave,
-                                                   RewardLds *rw = nullptr) {
+                                                   RewardLds *rw = nullptr, const uint32_t *lut = nullptr) {
+  static_assert(!LUT || TT > 0, "the nibble tables serve the stream with GEBV");
   static_assert(TT >= 0 && TT <= 2, "effects are held in registers across the trip");
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   constexpr int NT = TT > 0 ? TT : 1;
@@ -283,6 +307,10 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       dstp[r] = p.outp + (int64_t)c * p.nvp;
       dstb[r] = OBS ? p.outb + (int64_t)c * p.pitch : nullptr;
     }
+    __amdgpu_buffer_rsrc_t obs_rsrc[R];  // the rows' observation blocks (wave-uniform bases)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      obs_rsrc[r] = __builtin_amdgcn_make_buffer_rsrc((void *)dstb[r], 0, OBS ? (int)p.pitch : 0, 0x00020000);
     auto word_at = [](const uint16_t *base, uint32_t v) -> uint32_t {
       return *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(base) + 2u * v);
     };
@@ -325,58 +353,93 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       }
     };
     constexpr int AHEAD = TT == 0 ? kLongAhead : kShortAhead;
+    const char *plane[NT][3];  // the digit planes' bases: scalars, so that every digit load is base + one 32-bit offset
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        plane[q][j] = reinterpret_cast<const char *>(p.dig + ((int64_t)(p.t0 + q) * 3 + j) * ((int64_t)p.nvec + 1));
+      }
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
       uint4 dg[VPT][NT][3];
       if constexpr (TT > 0) {
 #pragma unroll
         for (int u = 0; u < VPT; ++u) {
-          const int vu = v + 64 * u < last ? v + 64 * u : last;
+          // a lane that redoes the row's last vector must not count it twice: it reads the zero block that ends every
+          // digit plane.  Plane bases are wave-uniform, the lanes address with one 32-bit offset.
+          const uint32_t vd = v + 64 * u < p.nvec ? (uint32_t)(v + 64 * u) : (uint32_t)p.nvec;
 #pragma unroll
-          for (int q = 0; q < TT; ++q) {
-            const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vu;
-            dg[u][q][0] = dp[0];
-            dg[u][q][1] = dp[p.nvec];
-            dg[u][q][2] = dp[2 * (int64_t)p.nvec];
-          }
+          for (int q = 0; q < TT; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dg[u][q][j] = *reinterpret_cast<const uint4 *>(plane[q][j] + 16u * vd);
         }
       }
       load_words(base + 64 * VPT * AHEAD, next);
+      typedef short short2v __attribute__((ext_vector_type(2)));
+      uint32_t pr[R][VPT][4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
+      uint4 oo[R][VPT];
+      // every lookup of the trip is asked for before the first is used: one LDS round trip per trip, not one per vector
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int u = 0; u < VPT; ++u) {
-          const bool has = v + 64 * u < p.nvec;
           const int vu = v + 64 * u < last ? v + 64 * u : last;
           uint32_t o = w.a[u][r];
-          if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
+          if constexpr (MODE == MODE_CROSS)
+            o = LUT ? cross16_raw(w.a[u][r], w.b[u][r], w.z[u][r]) : cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
-          const uint4 oo = expand_vector(o);
-          if constexpr (OBS) *reinterpret_cast<uint4 *>(dstb[r] + 16u * (uint32_t)vu) = oo;
-          if constexpr (TT > 0) {
-            {
-              typedef short short2v __attribute__((ext_vector_type(2)));
-              const uint32_t ww[4] = {oo.x, oo.y, oo.z, oo.w};
-              uint32_t pr[4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
-              // a lane that redid the last vector must not count it twice: its dosages are zeroed, not branched
-              // around (four branches per trip cost the configs[1] launch 0.6 of its 23.7 us)
-              const uint32_t hm = has ? 0x00FF00FFu : 0u;
+          if constexpr (LUT) {
+            // byte offsets of the word's four nibbles in a table of dwords: two instructions each, shared by both tables
+            const uint32_t at[4] = {(o << 2) & 0x3cu, (o >> 2) & 0x3cu, (o >> 6) & 0x3cu, (o >> 10) & 0x3cu};
+            const char *lb = reinterpret_cast<const char *>(lut);
+            if constexpr (OBS) {
+              oo[r][u].x = *reinterpret_cast<const uint32_t *>(lb + at[0]);
+              oo[r][u].y = *reinterpret_cast<const uint32_t *>(lb + at[1]);
+              oo[r][u].z = *reinterpret_cast<const uint32_t *>(lb + at[2]);
+              oo[r][u].w = *reinterpret_cast<const uint32_t *>(lb + at[3]);
+            }
 #pragma unroll
-              for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & hm;
+            for (int k = 0; k < 4; ++k) pr[r][u][k] = *reinterpret_cast<const uint32_t *>(lb + 4 * kNibbleLutDosage + at[k]);
+          } else {
+            oo[r][u] = expand_vector(o);
+            if constexpr (TT > 0) {
+              const uint32_t ww[4] = {oo[r][u].x, oo[r][u].y, oo[r][u].z, oo[r][u].w};
 #pragma unroll
-              for (int q = 0; q < TT; ++q)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                  const uint32_t dd[4] = {dg[u][q][j].x, dg[u][q][j].y, dg[u][q][j].z, dg[u][q][j].w};
-                  int a = acc[r][q][j];
-#pragma unroll
-                  for (int k = 0; k < 4; ++k)
-                    a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
-                  acc[r][q][j] = a;
-                }
+              for (int k = 0; k < 4; ++k) pr[r][u][k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
             }
           }
         }
+      if constexpr (OBS) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int u = 0; u < VPT; ++u) {
+            const int vu = v + 64 * u < last ? v + 64 * u : last;
+            // 16-byte stores through the row's buffer descriptor, so that the cache policy is an immediate the
+            // compiler knows (its waits stay counted): write-through (sc1, aux 16) or non-temporal (nt, aux 2)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 dv = {oo[r][u].x, oo[r][u].y, oo[r][u].z, oo[r][u].w};
+            __builtin_amdgcn_raw_buffer_store_b128(dv, obs_rsrc[r], (int)(16u * (uint32_t)vu), 0, OBSNT ? 2 : 16);
+          }
+      }
+      if constexpr (TT > 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int u = 0; u < VPT; ++u)
+#pragma unroll
+            for (int q = 0; q < TT; ++q)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                const uint32_t dd[4] = {dg[u][q][j].x, dg[u][q][j].y, dg[u][q][j].z, dg[u][q][j].w};
+                int a = acc[r][q][j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[r][u][k]), __builtin_bit_cast(short2v, dd[k]), a, false);
+                acc[r][q][j] = a;
+              }
+      }
     };
     if constexpr (AHEAD == 1) {
       Words wa, wb;
@@ -443,9 +506,12 @@ namespace bh {
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   __shared__ RewardLds rwl;
+  __shared__ uint32_t nib[kNibbleLutWords];
+  constexpr bool LUT = TT > 0 && TT <= 2;  // the stream with GEBV looks its bytes and dosages up (nibble_lut_init)
   prime_next_reward(p.reward_next, p.n_envs, p.reward_pitch);
-  if (p.reward) {
+  if (LUT || p.reward) {
     if (threadIdx.x == 0) reward_lds_init(&rwl);
+    if (LUT && threadIdx.x < 16) nibble_lut_init(nib, (int)threadIdx.x);
     __syncthreads();
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
@@ -466,10 +532,12 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
     if (p.outp && (TT > 0 || p.seq > 1)) {
       // with GEBV in the stream: two vectors per lane and trip when the observation is written too (-2.5 % at
       // 16 x 256 x 10k), one otherwise
-      if (p.outb)
-        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors>(p, (int)blockIdx.x, wave, &rwl);
+      if (p.outb && p.obs_nt)
+        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, true>(p, (int)blockIdx.x, wave, &rwl, nib);
+      else if (p.outb)
+        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(p, (int)blockIdx.x, wave, &rwl, nib);
       else
-        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : 1>(p, (int)blockIdx.x, wave, &rwl);
+        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : 1, LUT>(p, (int)blockIdx.x, wave, &rwl, nib);
       return;
     }
   }
@@ -487,6 +555,8 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
+  __shared__ uint32_t nib[kNibbleLutWords];
+  constexpr bool LUT = MW == 4 && TT > 0 && TT <= 2;  // nibble_lut_init
   if constexpr (MW == 4) {
     if (fp.out && (int)blockIdx.x >= (int)gridDim.x - fp.E) {  // uniform per workgroup
       founders_role(fp, (int)blockIdx.x - ((int)gridDim.x - fp.E), reinterpret_cast<uint64_t *>(lds_raw));
@@ -501,16 +571,19 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
       done = 0;
       reward_lds_init(&rwl);
     }
+    if (LUT && threadIdx.x < 16) nibble_lut_init(nib, (int)threadIdx.x);
     __syncthreads();
   }
   if (wave < 4) {
     if ((int)blockIdx.x < rp.n_blocks) {
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
-          if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors>(rp, (int)blockIdx.x, wave, &rwl);
+          if (rp.outb && rp.obs_nt)
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, true>(rp, (int)blockIdx.x, wave, &rwl, nib);
+          else if (rp.outb)
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(rp, (int)blockIdx.x, wave, &rwl, nib);
           else
-            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : 1>(rp, (int)blockIdx.x, wave, &rwl);
+            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : 1, LUT>(rp, (int)blockIdx.x, wave, &rwl, nib);
           return;
         }
       }

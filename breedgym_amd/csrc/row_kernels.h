@@ -69,7 +69,7 @@ struct RowParams {
   float *gebv;         // (rows, T) or null
   const uint8_t *Z;    // cross: (B, zpitch) masks from mask_kernel
   const double *eff;   // (tcount, effPitch) f64 marker effects of traits t0.., zero padded
-  const uint4 *dig;    // (T, 3, nvec) int16 digit planes of the fixed-point effects (row_role_pipelined)
+  const uint4 *dig;    // (T, 3, nvec + 1) int16 digit planes of the fixed-point effects (row_role_pipelined)
   const double *scale; // (T) 2^-s_t
   int64_t pitch;       // bytes per genotype row (multiple of 16)
   int64_t effPitch;    // doubles per trait (= 8 * nvec)
@@ -804,10 +804,10 @@ __device__ __forceinline__ void row_role_pipelined(const RowParams &p, const int
     uint4 dg[TT][3];
 #pragma unroll
     for (int q = 0; q < TT; ++q) {
-      const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * p.nvec + vv;
+      const uint4 *dp = p.dig + (int64_t)(p.t0 + q) * 3 * (p.nvec + 1) + vv;
       dg[q][0] = dp[0];
-      dg[q][1] = dp[p.nvec];
-      dg[q][2] = dp[2 * (int64_t)p.nvec];
+      dg[q][1] = dp[p.nvec + 1];
+      dg[q][2] = dp[2 * (int64_t)(p.nvec + 1)];
     }
     load_vecs(base + 64, next);
     uint4 oo[R];
