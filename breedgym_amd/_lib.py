@@ -124,6 +124,7 @@ SIGNATURES = {
     "bh_step_bind": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64]),
     "bh_step": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _u32p, _int]),
     "bh_gather_packed": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "bh_gather_packed_deferred": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "bh_key_from_seed": (None, [_c.c_uint64, _u32p]),
     "bh_set_threefry_layout": (_int, [_vp, _int]),
     "bh_set_mutation": (_int, [_vp, _c.c_float]),

@@ -1,5 +1,6 @@
 // libbreedhip.so -- the step/reset launches: bh_cross, bh_cross_packed, bh_gather, bh_gather_packed, bh_pack,
 // bh_gebv (dispatch over the GEBV routes), bh_reward_max.
+#include <cstdlib>
 #include "ctx.h"
 #include "mutation.h"
 #include "packed_kernels.h"
@@ -190,6 +191,19 @@ int launch_cross_mw(bh_ctx *c, const bh::RowParams &rp, const bh::MaskParams &mp
 constexpr int kRowsPerWavePacked = 2;  // rows one wave streams at once when there are many
 constexpr int kRowsPerWaveLong = 1;    // rows a wave interleaves in the long-row stream
 
+int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 ? 2 : tcount <= 4 ? 4 : 8; }
+
+// bh_gather_packed's arguments -> the launch it becomes (shared by the call itself and by the gather asked for ahead)
+struct GatherPlan {
+  bh::PackedParams p;
+  bool fused = false, mfma_after = false;
+  int turns = 0;
+};
+GatherPlan plan_gather(const bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
+                       uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv);
+int run_gather(bh_ctx *c, const GatherPlan &g, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
+               int64_t n_rows, float *d_gebv);
+
 template <int TT, int MW, int R>
 int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   const int per_wave = R * std::max(1, rp.seq);
@@ -198,6 +212,19 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
   size_t lds = mp.sites ? 0 : (size_t)mp.group_lds * (4 / MW);
   int grid = mp.sites ? rp.n_blocks
                       : (MW == 4 ? two_role_grid(rp.n_blocks, mp.n_blocks) : std::max(rp.n_blocks, mp.n_blocks));
+  bh::PackedParams gp{};  // n_blocks = 0: nothing rides
+  if (MW == 4 && TT >= 1 && TT <= 2 && !mp.sites && c->gather_ahead.pending) {
+    // a gather asked for ahead (the founders of the reset behind a horizon step) rides on this launch if it would
+    // have become the same kind of stream: packed rows out, its GEBV fused with this many traits, rows in twos or not
+    const auto &ga = c->gather_ahead;
+    const GatherPlan g = plan_gather(c, ga.src, ga.src_rows, ga.idx, ga.n_rows, ga.outp, ga.outb, ga.gebv);
+    if (g.fused && g.turns <= 1 && ga.outp && tt_for(g.p.tcount) == TT && (ga.n_rows >= 4096 ? 2 : 1) == R) {
+      gp = g.p;
+      gp.n_blocks = (gp.n_rows + 8 * R - 1) / (8 * R);  // all eight waves of a rider stream rows
+      grid += gp.n_blocks;
+      c->gather_ahead.pending = false;
+    }
+  }
   bh::FoundersParams fp{};
   if (MW == 4 && c->founders_pending && c->fp_pending.P <= 1024 && (size_t)c->fp_pending.P * 16 <= 48 * 1024) {
     fp = c->fp_pending;  // the draw rides on this launch: E more workgroups
@@ -205,7 +232,7 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
     grid += fp.E;
     lds = std::max(lds, (size_t)fp.P * 16);
   }
-  hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp);
+  hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
   if (mp.sites) return launch_mask_finish(c, mp);  // site words -> crossover masks
@@ -280,6 +307,7 @@ int mask_waves_for_runahead(const bh_ctx *c, int64_t B, int64_t rows) {
 // the slowest form (8192 rows: 67 us against 43) and non-temporal the fastest by far (16384 rows: 80 us against 140 for
 // plain stores, 32768: 163 against 280).
 int obs_store_nt(const bh_ctx *c, int64_t rows) { return rows * c->pitch > (int64_t)96 << 20; }
+
 
 // make d_Z[buf] hold at least `bytes`; growing it waits for everything that may still touch it
 int ensure_z(bh_ctx *c, int buf, int64_t bytes) {
@@ -381,7 +409,6 @@ int mutate_rows(bh_ctx *c, uint32_t key0, uint32_t key1, int64_t nkeys, KeyWindo
   return BH_OK;
 }
 
-int tt_for(int tcount) { return tcount <= 0 ? 0 : tcount == 1 ? 1 : tcount == 2 ? 2 : tcount <= 4 ? 4 : 8; }
 
 bh::RowParams base_params(const bh_ctx *c) {
   bh::RowParams p{};
@@ -471,7 +498,68 @@ int packed_gebv_chunks(bh_ctx *c, const uint16_t *d_rows, int64_t rows, float *d
   return BH_OK;
 }
 
+GatherPlan plan_gather(const bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
+                       uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv) {
+  GatherPlan g;
+  bh::PackedParams &p = g.p;
+  p = packed_params(c);
+  p.src = d_src;
+  p.outp = d_out_packed;
+  p.outb = d_out_bytes;
+  p.obs_nt = obs_store_nt(c, n_rows);
+  p.idx = d_idx;
+  p.gebv = d_gebv;
+  p.n_pool = (int32_t)src_rows;
+  p.n_rows = (int32_t)n_rows;
+  const bool writes = d_out_packed || d_out_bytes;
+  g.mfma_after = d_gebv && use_bits_gebv(c, n_rows) &&
+                 (c->T >= kMfmaGebvMinTraits || !writes || (d_out_packed && long_row_turns(c, n_rows) > 1));
+  g.fused = d_gebv && c->T <= kMaxFusedTraits && !g.mfma_after;
+  p.tcount = g.fused ? (int32_t)c->T : 0;
+  g.turns = (p.tcount == 0 && d_out_packed) ? long_row_turns(c, n_rows) : 0;
+  p.seq = g.turns;
+  return g;
+}
+
+int run_gather(bh_ctx *c, const GatherPlan &g, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
+               int64_t n_rows, float *d_gebv) {
+  const bh::PackedParams &p = g.p;
+  if (p.tcount > 0 || p.outp || p.outb) {
+    if (int rc = g.turns > 1 ? launch_prow_r<bh::MODE_GATHER, kRowsPerWaveLong>(c, p, 0)
+                             : launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount)))
+      return rc;
+  }
+  if (d_gebv && !g.fused) {
+    // the matrix-core pass straight over the source rows, through the index (gebv_bits.h)
+    if (g.mfma_after) return gebv_bits(c, d_src, src_rows, d_idx, n_rows, d_gebv);
+    // few rows or more than eight traits: f64 passes over the packed rows, through the index
+    for (int t0 = 0; t0 < c->T; t0 += kMaxFusedTraits) {
+      bh::PackedParams q = p;
+      q.outp = nullptr;
+      q.outb = nullptr;
+      q.t0 = t0;
+      q.tcount = (int32_t)std::min<int64_t>(kMaxFusedTraits, c->T - t0);
+      q.eff = c->d_eff + (int64_t)t0 * c->effPitch;
+      if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, q, tt_for(q.tcount))) return rc;
+    }
+  }
+  return BH_OK;
+}
+
 }  // namespace
+
+namespace bhh {
+
+// a gather asked for ahead that found no launch to ride on is made now, in stream order
+int flush_gather(bh_ctx *c) {
+  if (!c->gather_ahead.pending) return BH_OK;
+  c->gather_ahead.pending = false;
+  const auto ga = c->gather_ahead;
+  const GatherPlan g = plan_gather(c, ga.src, ga.src_rows, ga.idx, ga.n_rows, ga.outp, ga.outb, ga.gebv);
+  return run_gather(c, g, ga.src, ga.src_rows, ga.idx, ga.n_rows, ga.gebv);
+}
+
+}  // namespace bhh
 
 extern "C" {
 
@@ -811,54 +899,39 @@ int bh_pack(bh_ctx *c, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed
   return launch_pack(c, p);
 }
 
+static int check_gather_args(bh_ctx *c, const char *what, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
+                             int64_t n_rows, float *d_gebv) {
+  if (n_rows < 0 || src_rows < 0) return fail(BH_ERR_BAD_ARG, "%s: negative size", what);
+  if (n_rows == 0) return BH_OK;
+  if (!d_src) return fail(BH_ERR_BAD_ARG, "%s: null device pointer", what);
+  if (src_rows == 0) return fail(BH_ERR_BAD_ARG, "%s: empty source", what);
+  if (!d_idx && n_rows > src_rows) return fail(BH_ERR_BAD_ARG, "%s: more rows than the source holds", what);
+  if (n_rows > 0x3FFFFFFF || src_rows > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "%s: too many rows", what);
+  if (d_gebv && c->T == 0) return fail(BH_ERR_BAD_ARG, "%s: GEBV requested but the context has no traits", what);
+  return BH_OK;
+}
+
 int bh_gather_packed(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
                      uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv) {
   if (int rc = check_ctx(c)) return rc;
   if (int rc = flush_founders(c)) return rc;
-  if (n_rows < 0 || src_rows < 0) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: negative size");
+  if (int rc = check_gather_args(c, "bh_gather_packed", d_src, src_rows, d_idx, n_rows, d_gebv)) return rc;
   if (n_rows == 0) return BH_OK;
-  if (!d_src) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: null device pointer");
-  if (src_rows == 0) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: empty source");
-  if (!d_idx && n_rows > src_rows) return fail(BH_ERR_BAD_ARG, "bh_gather_packed: more rows than the source holds");
-  if (n_rows > 0x3FFFFFFF || src_rows > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_gather_packed: too many rows");
-  if (d_gebv && c->T == 0)
-    return fail(BH_ERR_BAD_ARG, "bh_gather_packed: GEBV requested but the context has no traits");
-  bh::PackedParams p = packed_params(c);
-  p.src = d_src;
-  p.outp = d_out_packed;
-  p.outb = d_out_bytes;
-  p.obs_nt = obs_store_nt(c, n_rows);
-  p.idx = d_idx;
-  p.gebv = d_gebv;
-  p.n_pool = (int32_t)src_rows;
-  p.n_rows = (int32_t)n_rows;
-  const bool writes = d_out_packed || d_out_bytes;
-  const bool mfma_after =
-      d_gebv && use_bits_gebv(c, n_rows) &&
-      (c->T >= kMfmaGebvMinTraits || !writes || (d_out_packed && long_row_turns(c, n_rows) > 1));
-  const bool fused = d_gebv && c->T <= kMaxFusedTraits && !mfma_after;
-  p.tcount = fused ? (int32_t)c->T : 0;
-  if (p.tcount > 0 || d_out_packed || d_out_bytes) {
-    const int turns = (p.tcount == 0 && d_out_packed) ? long_row_turns(c, n_rows) : 0;
-    p.seq = turns;
-    if (int rc = turns > 1 ? launch_prow_r<bh::MODE_GATHER, kRowsPerWaveLong>(c, p, 0)
-                           : launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount)))
-      return rc;
-  }
-  if (d_gebv && !fused) {
-    // the matrix-core pass straight over the source rows, through the index (gebv_bits.h)
-    if (mfma_after) return gebv_bits(c, d_src, src_rows, d_idx, n_rows, d_gebv);
-    // few rows or more than eight traits: f64 passes over the packed rows, through the index
-    for (int t0 = 0; t0 < c->T; t0 += kMaxFusedTraits) {
-      bh::PackedParams q = p;
-      q.outp = nullptr;
-      q.outb = nullptr;
-      q.t0 = t0;
-      q.tcount = (int32_t)std::min<int64_t>(kMaxFusedTraits, c->T - t0);
-      q.eff = c->d_eff + (int64_t)t0 * c->effPitch;
-      if (int rc = launch_prow_mode<bh::MODE_GATHER>(c, q, tt_for(q.tcount))) return rc;
-    }
-  }
+  const GatherPlan g = plan_gather(c, d_src, src_rows, d_idx, n_rows, d_out_packed, d_out_bytes, d_gebv);
+  return run_gather(c, g, d_src, src_rows, d_idx, n_rows, d_gebv);
+}
+
+int bh_gather_packed_deferred(bh_ctx *c, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx, int64_t n_rows,
+                              uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv) {
+  if (int rc = check_ctx(c)) return rc;
+  // a founder draw still pending may be what writes d_idx: then it is made now, in stream order; any other stays
+  // pending and rides with this gather (VecBreedGym's horizon step: the founders of the reset after the next one)
+  if (c->founders_pending && static_cast<const int32_t *>(c->fp_pending.out) == d_idx)
+    if (int rc = flush_founders_draw(c)) return rc;
+  if (int rc = flush_gather(c)) return rc;  // an earlier gather asked for ahead
+  if (int rc = check_gather_args(c, "bh_gather_packed_deferred", d_src, src_rows, d_idx, n_rows, d_gebv)) return rc;
+  if (n_rows == 0) return BH_OK;
+  c->gather_ahead = {d_src, src_rows, d_idx, n_rows, d_out_packed, d_out_bytes, d_gebv, true};
   return BH_OK;
 }
 

@@ -105,6 +105,18 @@ struct bh_ctx {
   // a founder draw asked for ahead (bh_founders_deferred): rides on the next two-role launch, or gets its own
   bh::FoundersParams fp_pending{};
   bool founders_pending = false;
+  // a gather asked for ahead (bh_gather_packed_deferred): rides on the next two-role launch of bit-plane rows with its
+  // GEBV in the stream (packed_cross_kernel, gp), or is made by whatever comes first (flush_founders)
+  struct {
+    const uint16_t *src = nullptr;
+    int64_t src_rows = 0;
+    const int32_t *idx = nullptr;
+    int64_t n_rows = 0;
+    uint16_t *outp = nullptr;
+    uint8_t *outb = nullptr;
+    float *gebv = nullptr;
+    bool pending = false;
+  } gather_ahead;
   // reward chaining (bh_cross*): the buffer the last launch left holding -inf, ready to take atomic maxima
   const float *primed_reward = nullptr;
   int64_t primed_envs = 0, primed_pitch = 0;
@@ -132,7 +144,10 @@ int gebv_mfma(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv);
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv);
 int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv);
 
-// select.hip: a deferred founder draw that found no launch to ride on is made now, in stream order
+// select.hip: a deferred founder draw that found no launch to ride on is made now, in stream order -- and behind it a
+// gather asked for ahead that found none (cross.hip)
 int flush_founders(bh_ctx *c);
+int flush_founders_draw(bh_ctx *c);  // the draw alone
+int flush_gather(bh_ctx *c);
 
 }  // namespace bhh

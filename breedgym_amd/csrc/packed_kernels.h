@@ -23,6 +23,7 @@ namespace bh {
 constexpr int kLongRowPrio = 2;  // priority of the row waves of the long-row stream
 constexpr int kLongRowVectors = 4;   // vectors per lane and trip in the long-row stream
 constexpr int kShortRowVectors = 2;  // ... and in the stream with GEBV
+constexpr int kNoObsVectors = 1;     // ... with GEBV but without the byte observation (2: the same; 4: +6 us per launch)
 constexpr int kLongAhead = 1, kShortAhead = 1;  // trips the stream requests ahead: without / with GEBV
 
 // the sum of `v` over the wave's 64 lanes (it forms in lane 63 and is handed to all): four DPP steps
@@ -245,7 +246,9 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 // gebv_bits.h).  p.seq row groups per wave, one after the other: that keeps the grid of a launch of many
 // long rows small enough to be resident at once (not a question of DRAM pages: stores run at the same rate for
 // 512 ... 8192 concurrent row streams, tools/store_streams.hip).
-template <int TT, int MODE, int R, bool OBS, int VPT = 1, bool LUT = false, bool OBSNT = false>
+// WPB: waves of a workgroup that stream rows (four beside four mask waves; all eight in the workgroups of a gather that
+// rides on a cross launch, packed_cross_kernel).
+template <int TT, int MODE, int R, bool OBS, int VPT = 1, bool LUT = false, bool OBSNT = false, int WPB = 4>
 __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave,
                                                    RewardLds *rw = nullptr, const uint32_t *lut = nullptr) {
   static_assert(!LUT || TT > 0, "the nibble tables serve the stream with GEBV");
@@ -257,7 +260,8 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   // without GEBV the stream is almost all memory instructions: above the mask waves it keeps the memory pipeline
   // fed and they take every issue slot it leaves (their role has no vector loads to be starved of, mask_stream.h)
   if constexpr (TT == 0) __builtin_amdgcn_s_setprio(kLongRowPrio);
-  const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * 4 + wave) * R * seq);
+  static_assert(WPB == 4 || MODE == MODE_GATHER, "the reward's workgroup layout counts four row waves");
+  const int first = __builtin_amdgcn_readfirstlane((xcd_row(block, p.n_blocks) * WPB + wave) * R * seq);
   // the traits' scales are asked for here: read where they are used -- after the last trip, by one lane -- they cost
   // every wave a memory round trip at the very end of its life (a microsecond of the configs[1] launch)
   double scale[NT];
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
       else if (p.outb)
         packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(p, (int)blockIdx.x, wave, &rwl, nib);
       else
-        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : 1, LUT>(p, (int)blockIdx.x, wave, &rwl, nib);
+        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors, LUT>(p, (int)blockIdx.x, wave, &rwl, nib);
       return;
     }
   }
@@ -551,19 +555,53 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 // between the horizon step and the founder gather.
 template <int TT, int MW, int R>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp,
-                                                          const FoundersParams fp) {
+                                                          const FoundersParams fp, const PackedParams gp) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
   __shared__ uint32_t nib[kNibbleLutWords];
   constexpr bool LUT = MW == 4 && TT > 0 && TT <= 2;  // nibble_lut_init
+  int n_main = (int)gridDim.x;  // two-role workgroups
+  int block = (int)blockIdx.x;  // ... and which of them this is
+  bool riding = false;          // a workgroup of the gather that rides on this launch (gp)
   if constexpr (MW == 4) {
-    if (fp.out && (int)blockIdx.x >= (int)gridDim.x - fp.E) {  // uniform per workgroup
-      founders_role(fp, (int)blockIdx.x - ((int)gridDim.x - fp.E), reinterpret_cast<uint64_t *>(lds_raw));
+    // fp.out != null: fp.E workgroups of the grid draw the founders of a reset to come (founders_role: 12 us of LDS
+    // sorting that would otherwise be a launch of its own).  They are the last of the grid -- the row work is not held
+    // up -- unless a gather rides too: that launch runs its workgroups in two rounds, and a draw that starts with the
+    // first ends long before the second does
+    const int nf = fp.out ? fp.E : 0;
+    const bool f_first = LUT && gp.n_blocks > 0;
+    n_main -= nf;
+    if (nf > 0 && (f_first ? block < nf : block >= n_main)) {  // uniform per workgroup
+      founders_role(fp, f_first ? block : block - n_main, reinterpret_cast<uint64_t *>(lds_raw));
       return;
     }
+    if (f_first) block -= nf;
+    if constexpr (LUT) {
+      // gp.n_blocks > 0: a gather asked for ahead (bh_gather_packed_deferred: the founders of the reset that follows
+      // this horizon step) rides on this launch as gp.n_blocks more workgroups, all eight waves of which stream
+      // gathered rows (bit planes, byte observation, GEBV).  Eights of two-role workgroups and eights of riders
+      // alternate for as long as both last: the riders' stores (the observation) flow from the first microsecond
+      // beside the crosses, which at a horizon write no observation, and blockIdx % 8 -- the XCD -- stays what xcd_row
+      // expects of a workgroup's number.  At 16 x 256 x 10k the launch takes 31 us (a horizon launch 17.8 + a gather
+      // launch 18 + the gap between them before): its 784 workgroups are two rounds of latency chains (a wave's rows
+      // are ten trips, each a round trip to memory), whichever way the riders are cut -- four row waves in two rounds
+      // 31.7, half as many with two row groups each 31.7, eight row waves 31.2 (profiles/r04_fused_reset.txt).
+      if (gp.n_blocks > 0) {
+        n_main -= gp.n_blocks;
+        const int both = (n_main < gp.n_blocks ? n_main : gp.n_blocks) & ~7;
+        if (block < 2 * both) {
+          riding = (block >> 3) & 1;
+          block = ((block >> 4) << 3) | (block & 7);
+        } else {
+          const int rest = block - 2 * both;
+          riding = rest >= n_main - both;
+          block = both + (riding ? rest - (n_main - both) : rest);
+        }
+      }
+    }
   }
-  prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch);
+  prime_next_reward(rp.reward_next, rp.n_envs, rp.reward_pitch, block == 0 && !riding);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
   if (MW == 4 || rp.reward) {  // uniform: the whole workgroup meets here or nowhere
     if (threadIdx.x == 0) {
@@ -574,31 +612,41 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     if (LUT && threadIdx.x < 16) nibble_lut_init(nib, (int)threadIdx.x);
     __syncthreads();
   }
+  if constexpr (LUT) {
+    if (riding) {  // all eight waves stream rows: a rider has no mask work
+      if (gp.outb && gp.obs_nt)
+        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, true, true, 8>(gp, block, wave, &rwl, nib);
+      else if (gp.outb)
+        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, true, false, 8>(gp, block, wave, &rwl, nib);
+      else
+        packed_stream_role<TT, MODE_GATHER, R, false, 1, true, false, 8>(gp, block, wave, &rwl, nib);
+      return;
+    }
+  }
   if (wave < 4) {
-    if ((int)blockIdx.x < rp.n_blocks) {
+    if (block < rp.n_blocks) {
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
           if (rp.outb && rp.obs_nt)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, true>(rp, (int)blockIdx.x, wave, &rwl, nib);
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, true>(rp, block, wave, &rwl, nib);
           else if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(rp, (int)blockIdx.x, wave, &rwl, nib);
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(rp, block, wave, &rwl, nib);
           else
-            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : 1, LUT>(rp, (int)blockIdx.x, wave, &rwl, nib);
+            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors, LUT>(rp, block, wave, &rwl, nib);
           return;
         }
       }
-      packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, (int)blockIdx.x, wave, &rwl);
+      packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, block, wave, &rwl);
     }
   } else if constexpr (MW == 1) {
-    if ((int)blockIdx.x < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, (int)blockIdx.x, wave - 4, lds_raw, nullptr);
+    if (block < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, block, wave - 4, lds_raw, nullptr);
   } else {
     if (mp.sites) {  // long rows: one gamete stream per lane, site words to memory (mask_stream.h)
-      mask_stream_role(mp, (int)blockIdx.x * 4 + wave - 4, ((int)gridDim.x - (fp.out ? fp.E : 0)) * 4);
+      mask_stream_role(mp, block * 4 + wave - 4, n_main * 4);
       return;
     }
-    const int n_main = (int)gridDim.x - (fp.out ? fp.E : 0);  // without the workgroups that draw founders
     int iter = 0;  // crosses in turns when the grid is shorter than the mask work (cross_kernel)
-    for (int mb = (int)blockIdx.x; mb < mp.n_blocks; mb += n_main, ++iter)
+    for (int mb = block; mb < mp.n_blocks; mb += n_main, ++iter)
       mask_role<4, SYNC_COUNTER>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
   }
 }

@@ -158,8 +158,12 @@ __device__ __forceinline__ void reward_wg_layout(int block, int n_blocks, int pe
 }
 
 // what the first workgroup of every launch does for the launch after it
+__device__ __forceinline__ void prime_next_reward(float *reward_next, int n_envs, int64_t pitch, bool first);
 __device__ __forceinline__ void prime_next_reward(float *reward_next, int n_envs, int64_t pitch) {
-  if (reward_next && blockIdx.x == 0)
+  prime_next_reward(reward_next, n_envs, pitch, blockIdx.x == 0);
+}
+__device__ __forceinline__ void prime_next_reward(float *reward_next, int n_envs, int64_t pitch, bool first) {
+  if (reward_next && first)
     for (int64_t i = threadIdx.x; i < n_envs; i += blockDim.x) reward_next[i * pitch] = -INFINITY;
 }
 

@@ -406,10 +406,15 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
 namespace bhh {
 
 // a deferred founder draw that found no launch to ride on is made now, in stream order
-int flush_founders(bh_ctx *c) {
+int flush_founders_draw(bh_ctx *c) {
   if (!c->founders_pending) return BH_OK;
   c->founders_pending = false;
   return launch_founders(c, c->fp_pending);
+}
+
+int flush_founders(bh_ctx *c) {
+  if (int rc = flush_founders_draw(c)) return rc;
+  return flush_gather(c);  // (its indices may be what that draw wrote)
 }
 
 }  // namespace bhh

@@ -512,13 +512,15 @@ class HipEngine(EngineBase):
             return None
         return StepRing(self, n_envs, n_out, with_observations, max_slots)
 
-    def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None) -> None:
-        """Rows ``idx`` (or 0..n_rows-1) of packed ``src`` -> packed and/or byte-layout rows and/or GEBV."""
+    def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None, deferred=False) -> None:
+        """Rows ``idx`` (or 0..n_rows-1) of packed ``src`` -> packed and/or byte-layout rows and/or GEBV.
+        ``deferred``: asked for ahead of a ``cross_packed`` / ``StepRing.step`` call, whose launch then makes the gather
+        as well (bh_gather_packed_deferred); the caller keeps every tensor alive until that call."""
         assert idx is None or (idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == n_rows)
         assert out_packed is None or out_packed.shape[0] >= n_rows
         assert out_bytes is None or out_bytes.shape[0] >= n_rows
         _lib.check(
-            self._L.bh_gather_packed(
+            (self._L.bh_gather_packed_deferred if deferred else self._L.bh_gather_packed)(
                 self._h, src.data_ptr(), src.shape[0], _ptr(idx), int(n_rows), _ptr(out_packed), _ptr(out_bytes),
                 _ptr(gebv),
             )

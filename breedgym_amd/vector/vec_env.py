@@ -123,7 +123,13 @@ class VecBreedGym(_VectorEnvBase):
         self._stage, self._stage_turn = {}, 0  # pinned staging blocks for host actions, two per shape, used in turn
         self._ring = None  # StepRing: the output blocks of step(), kept and reused (storage="bits" on the HIP engine)
         self._all_false, self._all_true = np.full(self.num_envs, False), np.full(self.num_envs, True)
-        self._founders_ahead = None  # (indices, key after the draw) made by the horizon step's launch for its reset
+        # (indices, key after the draw, bytes of the key drawn from) of the next reset's founders, made by the launch of
+        # the step before the horizon (or by the horizon step's, when nothing was made by then)
+        self._founders_ahead = None
+        # (slot, what keeps it taken, key after the draw, bytes of the key drawn from): the next reset's founder
+        # population, gathered by the horizon step's launch into a slot of the ring
+        self._reset_ahead = None
+        self._founders_next = None  # the founders of the reset after that one, drawn by the same launch
         self._rew_primed = None  # (E,) f32 the last cross launch left holding -inf: the next step's reward buffer
         self.step_idx = None
         self.reset_infos = {}
@@ -234,11 +240,26 @@ class VecBreedGym(_VectorEnvBase):
         ring = self._ring
         if ring is not None and n_out == ring.n_out and self._prows is not None:
             # ---- the usual step: one C call into a block nobody holds any more, nothing allocated (engine.StepRing)
-            if done and self.autoreset:
-                # the reset that follows needs its founders: their draw depends on the env key only and rides on
-                # this step's launch instead of being a launch of its own (bh_founders_deferred)
-                self._founders_ahead = eng.founders(self.random_key, E, len(self.germplasm), self.individual_per_gen,
-                                                    deferred=True)
+            if self.autoreset and (done or self.step_idx + 2 == self.num_generations):
+                # the reset behind the horizon needs its founders: their draw depends on the env key only and rides on
+                # a step's launch instead of being a launch of its own (bh_founders_deferred) -- on the launch of the
+                # step BEFORE the horizon, so that the horizon step's launch can already gather them: its crosses
+                # write no observation, the gathered founders do, and one launch does both instead of two half-empty
+                # ones (bh_gather_packed_deferred).  A key somebody advanced in between (SelectionScores does, per
+                # step) voids what was made ahead; the draw then rides on the horizon launch and reset() gathers.
+                ahead = self._founders_ahead
+                if ahead is not None and not (ahead[2] == np.ascontiguousarray(self.random_key, np.uint32).tobytes()
+                                              and ahead[0].numel() == E * self.individual_per_gen):
+                    ahead = self._founders_ahead = None
+                if ahead is None:
+                    self._founders_ahead = self._draw_founders(deferred=True)
+                elif done and self._ring is not None and self._germ_prows is not None:
+                    # ... and the same launch draws the founders of the reset AFTER that one (from the key that draw
+                    # left): the next horizon finds them made, no step in between carries a draw
+                    nxt = self._draw_founders(deferred=True, key=ahead[1])
+                    self._reset_ahead = self._gather_ahead(ahead)
+                    if self._reset_ahead is not None:
+                        self._founders_next = nxt
             # at the horizon the observation handed out is the next episode's first one (vec_env.py:102-107):
             # this generation's byte layout would be written for nobody
             want_obs = self.observations == "eager" and not (done and self.autoreset)
@@ -283,8 +304,7 @@ class VecBreedGym(_VectorEnvBase):
                 rew_dev = eng.empty_reward(E)  # not primed: the library fills it first
         if self.storage == "bits":
             if done and self.autoreset and not founders_drawn:
-                self._founders_ahead = eng.founders(self.random_key, E, len(self.germplasm), self.individual_per_gen,
-                                                    deferred=True)
+                self._founders_ahead = self._draw_founders(deferred=True)
             want_obs = self.observations == "eager" and not (done and self.autoreset)
             if self._fast_step:
                 key = sim.random_key
@@ -308,6 +328,31 @@ class VecBreedGym(_VectorEnvBase):
             self._adopt(out, n_out)
         self._rew_primed = rew_next
         return self._close_step({"GEBV": gebv.as_subclass(DeviceArray)}, rew_dev)
+
+    def _draw_founders(self, deferred=False, key=None):
+        """The founder draw of a reset from the env key as it stands (or ``key``) -> (indices, key after, bytes of the
+        key drawn from)."""
+        key = np.ascontiguousarray(self.random_key if key is None else key, np.uint32)
+        idx, new_key = self.simulator.engine.founders(key, self.num_envs, len(self.germplasm), self.individual_per_gen,
+                                                      deferred=deferred)
+        return idx, new_key, key.tobytes()
+
+    def _gather_ahead(self, ahead):
+        """The founders of the next reset (drawn already: ``ahead``) gathered into a slot of the ring by the launch of
+        the cross call that follows -> what ``reset`` needs to adopt them, or None (no slot to be had)."""
+        ring, eng = self._ring, self.simulator.engine
+        E, n = self.num_envs, self.individual_per_gen
+        if ring is None or (ring.n_envs, ring.n_out) != (E, n) or self._germ_prows is None:
+            return None
+        slot = ring.take()
+        if slot is None:
+            return None
+        # (the founders' GEBV goes to a block of its own, not the slot's: reset_infos keeps it until the next reset, and
+        # holding the slot's view that long would keep the slot out of use)
+        gebv = eng.empty((E, n, eng.n_traits), torch.float32).as_subclass(DeviceArray)
+        hold = (ring.state[slot], gebv, ahead[0])  # a slot is taken for as long as something of it is referenced
+        eng.gather_packed(self._germ_prows, ahead[0], E * n, ring.state[slot], ring.obs_rows[slot], gebv, deferred=True)
+        return slot, hold, ahead[0], ahead[1], ahead[2]
 
     def _close_step(self, infos, rew_dev=None):
         """What follows the new generation in any kind of step (vec_env.py:92-107): the generation is counted, the
@@ -342,8 +387,23 @@ class VecBreedGym(_VectorEnvBase):
         eng = self.simulator.engine
         E, n = self.num_envs, self.individual_per_gen
         ahead, self._founders_ahead = self._founders_ahead, None
-        if ahead is not None and seed is None and ahead[0].numel() == E * n:
-            idx, self.random_key = ahead  # drawn by the horizon step's launch from this same key
+        made, self._reset_ahead = self._reset_ahead, None
+        key_now = np.ascontiguousarray(self.random_key, np.uint32).tobytes()
+        if (made is not None and seed is None and self._ring is not None and made[4] == key_now
+                and (self._ring.n_envs, self._ring.n_out) == (E, n) and self.storage == "bits"):
+            # the horizon step's launch gathered this very population already (_gather_ahead)
+            slot, hold, _, self.random_key, _ = made
+            self._founders_ahead, self._founders_next = self._founders_next, None
+            ring = self._ring
+            self._prows, self._brows, self._populations, self._n = (ring.state[slot], ring.obs_rows[slot],
+                                                                    ring.populations[slot], n)
+            self._rew_primed = None
+            self.reset_infos = {"GEBV": hold[1]}
+            return (self._populations if self.observations == "eager" else ring.lazy[slot]), self.reset_infos
+        del made
+        self._founders_next = None
+        if ahead is not None and seed is None and ahead[0].numel() == E * n and ahead[2] == key_now:
+            idx, self.random_key = ahead[0], ahead[1]  # drawn by a step's launch from this same key
         else:
             idx, self.random_key = eng.founders(self.random_key, E, len(self.germplasm), n)
         if self.storage == "bits":
@@ -359,14 +419,15 @@ class VecBreedGym(_VectorEnvBase):
             slot = self._ring.take() if self._ring is not None else None
             if slot is not None:
                 ring = self._ring
-                gebv = ring.gebv[slot]
+                # (a block of its own, not the slot's: holding the slot's GEBV view until the next reset would keep the
+                # slot out of use)
+                gebv = eng.empty((E, n, eng.n_traits), torch.float32).as_subclass(DeviceArray)
                 eng.gather_packed(self._germ_prows, idx, E * n, ring.state[slot], ring.obs_rows[slot], gebv)
                 self._prows, self._brows, self._populations, self._n = (ring.state[slot], ring.obs_rows[slot],
                                                                         ring.populations[slot], n)
                 self._rew_primed = None
-                # (a copy: holding the slot's own GEBV view until the next reset would keep the slot out of use)
-                self.reset_infos = {"GEBV": DeviceArray.wrap(gebv.as_subclass(torch.Tensor).clone())}
-                return (self._populations if self.observations == "eager" else ring.lazy[slot]), {"GEBV": gebv}
+                self.reset_infos = {"GEBV": gebv}
+                return (self._populations if self.observations == "eager" else ring.lazy[slot]), self.reset_infos
             gebv = eng.empty((E, n, eng.n_traits), torch.float32)
             prows = eng.empty_packed(E * n)
             rows = eng.empty_population(E * n) if self.observations == "eager" else None
@@ -421,7 +482,7 @@ class VecBreedGym(_VectorEnvBase):
         self.step_idx = int(state["step_idx"])
         self.random_key = np.array(state["random_key"], np.uint32).copy()
         self.simulator.random_key = np.array(state["simulator_key"], np.uint32).copy()
-        self._founders_ahead, self._rew_primed = None, None
+        self._founders_ahead, self._founders_next, self._reset_ahead, self._rew_primed = None, None, None, None
 
     def close(self, **kwargs):
         if self._ring is not None:

@@ -259,6 +259,15 @@ int bh_step(bh_ctx *ctx, int64_t slot, int64_t reward_slot, int64_t prime_slot, 
  * d_out_packed, d_out_bytes, d_gebv may be NULL. */
 int bh_gather_packed(bh_ctx *ctx, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
                      int64_t n_rows, uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv);
+/* bh_gather_packed, asked for AHEAD of a bh_cross_packed / bh_step call: the rows are written by the next two-role
+ * launch of the context (its grid grows by the gather's workgroups; bit-plane rows out, GEBV of one or two traits in
+ * the stream) or, failing that, by a launch of their own before anything else of this context runs.  The reference
+ * has no counterpart (its reset, vec_env.py:109-129, follows its step); VecBreedGym's horizon step uses it when the
+ * founders of the reset behind it are already drawn: that step's crosses write no observation (the step hands out
+ * the next episode's first one, vec_env.py:102-107), the gather's rows do, and one launch does both instead of two
+ * half-empty ones.  What the gather writes must not be anything that call reads or writes. */
+int bh_gather_packed_deferred(bh_ctx *ctx, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
+                              int64_t n_rows, uint16_t *d_out_packed, uint8_t *d_out_bytes, float *d_gebv);
 
 /* Selection indices of the reference (breedgym/utils/index_functions.py:21-78): the optimal haploid of
  * every individual and its value.  d_pop (n_rows, pitch).  n_blocks == 0: marker m of the optimal

@@ -133,7 +133,7 @@ class OracleEngine(EngineBase):
         if out_bytes is not None:
             out_bytes[: n_envs * n_out] = tmp
 
-    def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None):
+    def gather_packed(self, src, idx, n_rows, out_packed=None, out_bytes=None, gebv=None, deferred=False):
         if idx is None:
             idx = torch.arange(n_rows, dtype=torch.int32)
         tmp = self.empty_population(n_rows)

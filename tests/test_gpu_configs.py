@@ -798,3 +798,88 @@ def test_pair_actions_of_a_multi_trait_outer_sum(rng):
     got = eng.pair_actions(torch.from_numpy(scores), n).cpu().numpy()
     ref = _pair_actions_restated(scores.reshape(E, -1), n)
     assert np.array_equal(got, ref) and ref.max() >= n  # indices beyond the generation do occur
+
+
+# ---- the reset gathered by the horizon step's launch (bh_gather_packed_deferred) -----------------------
+
+
+@pytest.mark.parametrize("E,n,M,T,G,observations", [
+    (3, 24, 2000, 1, 3, "eager"),      # few rows: one row per wave
+    (16, 256, 1000, 2, 2, "eager"),    # 4096 rows: two rows per wave, two traits, the draw rides on step 1 of 2
+    (5, 40, 1237, 1, 4, "lazy"),       # no byte observation, ragged row length
+    (4, 33, 520, 2, 1, "eager"),       # every step is a horizon: nothing can be made a step ahead
+    (2, 16, 300, 3, 3, "eager"),       # three traits: the GEBV is a pass of its own, the gather gets a launch of its own
+])
+def test_reset_made_by_the_horizon_launch_equals_oracle_chain(E, n, M, T, G, observations):
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    N = max(50, n + 7)
+    gm = synthetic_genetic_map(M, n_chr=3, n_traits=T, seed=4)
+    geno = synthetic_genotypes(N, M, seed=6)
+    env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, num_generations=G,
+                      reward_shaping=True, genetic_map=gm, observations=observations)
+    pop, info = env.reset(seed=9)
+    f, env_key = co.founders(co.key_from_seed(9), E, N, n)
+    ref = geno.view(np.uint8)[f]
+    sim_key = co.key_from_seed(9)
+    arng = np.random.default_rng(8)
+    kept = []  # what a caller keeps must stay what it was (the ring hands the horizon's blocks out of three slots)
+    for step in range(3 * G + 1):  # three horizons
+        a = arng.integers(0, n, (E, n, 2), dtype=np.int32)
+        pop, rews, ter, tru, info = env.step(a)
+        ref, sim_key = co.cross(ref, a, gm.recombination_vec, sim_key, 0)
+        g64 = co.gebv(ref, gm.marker_effects, want64=True)[1]
+        assert gebv_close(np.asarray(info["GEBV"]), g64), f"step {step}"
+        assert np.allclose(rews, g64.max(axis=(1, 2)), rtol=GEBV_RTOL)
+        assert np.array_equal(env.simulator.random_key, sim_key)
+        if (step + 1) % G == 0:
+            assert tru.all() and env.step_idx == 0
+            f, env_key = co.founders(env_key, E, N, n)
+            ref = geno.view(np.uint8)[f]
+            assert gebv_close(np.asarray(env.reset_infos["GEBV"]), co.gebv(ref, gm.marker_effects, want64=True)[1])
+        assert np.array_equal(u8(pop), ref), f"step {step}"
+        assert np.array_equal(env.random_key, env_key)
+        assert np.array_equal(u8(env.simulator.engine.as_genotypes(env.simulator.engine.unpack(env._prows), E, n)), ref)
+        kept.append((pop, ref.copy(), info["GEBV"], g64))
+    for pop, r, g, g64 in kept[-4:]:
+        assert np.array_equal(u8(pop), r)
+        assert gebv_close(np.asarray(g), g64)
+
+
+def test_reset_made_ahead_is_dropped_when_the_key_or_the_seed_changes():
+    """Founders drawn a step ahead belong to the env key they were drawn from: a wrapper that advances the key per step
+    (SelectionScores), a reset(seed=...) by hand and set_state all void them; results stay the oracle's."""
+    from breedgym_amd import VecBreedGym, rng
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    E, n, M, N, G = 4, 32, 800, 40, 3
+    gm = synthetic_genetic_map(M, n_chr=2, n_traits=1, seed=4)
+    geno = synthetic_genotypes(N, M, seed=6)
+    env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n, num_generations=G,
+                      reward_shaping=True, genetic_map=gm)
+    env.reset(seed=1)
+    f, env_key = co.founders(co.key_from_seed(1), E, N, n)
+    ref = geno.view(np.uint8)[f]
+    sim_key = co.key_from_seed(1)
+    arng = np.random.default_rng(3)
+    for step in range(2 * G):
+        a = arng.integers(0, n, (E, n, 2), dtype=np.int32)
+        # somebody advances the env key before every step, as SelectionScores' shuffle does
+        env.random_key = rng.split(env.random_key, 2, env.simulator.threefry_layout)[0]
+        env_key = co.split(env_key, 2)[0]
+        pop, rews, ter, tru, info = env.step(a)
+        ref, sim_key = co.cross(ref, a, gm.recombination_vec, sim_key, 0)
+        if (step + 1) % G == 0:
+            f, env_key = co.founders(env_key, E, N, n)
+            ref = geno.view(np.uint8)[f]
+        assert np.array_equal(u8(pop), ref), f"step {step}"
+        assert np.array_equal(env.random_key, env_key)
+    # a reset by hand with a seed, one step before a horizon (founders are drawn ahead by then)
+    for step in range(G - 1):
+        env.step(arng.integers(0, n, (E, n, 2), dtype=np.int32))
+    assert env._founders_ahead is not None
+    pop, _ = env.reset(seed=77)
+    f, env_key = co.founders(co.key_from_seed(77), E, N, n)
+    assert np.array_equal(u8(pop), geno.view(np.uint8)[f])
+    assert np.array_equal(env.random_key, env_key)
