@@ -232,6 +232,18 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
     grid += fp.E;
     lds = std::max(lds, (size_t)fp.P * 16);
   }
+  if (MW == 4 && TT == 1 && c->T == 1 && !mp.sites) {
+    // one trait, rows short enough: the row waves keep a copy of its digit planes in LDS (packed_stream_role, DIGLDS)
+    // -- where two workgroups per CU still fit beside everything else (48 bytes per eight markers: 59 KB at 10k)
+    const size_t dig = ((size_t)48 * (c->nvec + 1) + 1023) / 1024 * 1024;
+    const size_t at = (lds + 15) / 16 * 16;
+    if (at + dig <= 76 * 1024) {
+      rp.dig_lds = (int32_t)at + 1;
+      if (gp.n_blocks > 0) gp.dig_lds = rp.dig_lds;
+      lds = at + dig;
+      if (int rc = allow_big_lds(c, bh::packed_cross_kernel<TT, MW, R>, lds)) return rc;
+    }
+  }
   hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));

@@ -64,6 +64,8 @@ struct PackedParams {
   float *reward_next;  // (n_envs) set to -inf by this launch for a later one, or null
   int64_t reward_pitch;  // floats between the words of two envs in both (RowParams)
   int32_t n_envs;
+  int32_t dig_lds;  // 1 + byte offset, in the launch's dynamic LDS, of a copy of trait 0's three digit planes that the
+                    // row waves of a workgroup make and read (packed_stream_role, DIGLDS); 0 = digits from memory
   int32_t obs_nt;  // how the pipelined stream stores the byte observation: 0 write-through (sc1), 1 non-temporal
                    // (obs_store_policy in cross.hip)
   char *spare;  // 16 KB nobody reads: where the lanes past a row's end send their stores in the LDS-DMA stream
@@ -88,27 +90,6 @@ __device__ __forceinline__ uint4 expand_vector(uint32_t o16) {
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 __device__ __forceinline__ uint32_t cross16(uint32_t p0, uint32_t p1, uint32_t z) {
   return bfi(0x5555u, bfi(z, p0 >> 1, p0), bfi(z, p1, p1 << 1)) & 0xffffu;
-}
-
-// The same word without the final `& 0xffff`: for users that only look at its low 16 bits.
-__device__ __forceinline__ uint32_t cross16_raw(uint32_t p0, uint32_t p1, uint32_t z) {
-  return bfi(0x5555u, bfi(z, p0 >> 1, p0), bfi(z, p1, p1 << 1));
-}
-
-// Two 16-entry tables in LDS, indexed by a nibble of an offspring word = two markers (bits a0 a1 of marker 2k, then of
-// marker 2k+1): [0..15] the nibble's four bytes of the byte layout (what expand_dword computes), [272..287] the two
-// markers' dosages as two int16 (what the in-stream GEBV feeds v_dot2_i32_i16).  A lookup is a ds_read_b32 whose lanes
-// either agree (broadcast) or hit different banks (16 entries on 16 banks): conflict-free whatever the genotypes, and
-// it replaces 6 vector-ALU instructions per nibble (bfe, mul, and; shift, add, and) with 2 (the entry's address) in a
-// launch whose stream runs at the pace of VALU issue.
-constexpr int kNibbleLutDosage = 272;  // dwords between the two tables: beyond a ds_read2_b32's reach (255), not a
-                                       // multiple of 64 (ds_read2st64): fused, the pair lands in two neighbouring
-                                       // registers and the four dwords of a vector have to be moved together again
-constexpr int kNibbleLutWords = kNibbleLutDosage + 16;
-__device__ __forceinline__ void nibble_lut_init(uint32_t *lut, int i) {  // threads 0..15, before a workgroup barrier
-  const uint32_t n = (uint32_t)i & 15u;
-  lut[n] = ((n * 0x00204081u) & 0x01010101u);
-  lut[kNibbleLutDosage + n] = ((n & 1u) + ((n >> 1) & 1u)) | ((((n >> 2) & 1u) + (n >> 3)) << 16);
 }
 
 // One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
@@ -248,10 +229,17 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 // 512 ... 8192 concurrent row streams, tools/store_streams.hip).
 // WPB: waves of a workgroup that stream rows (four beside four mask waves; all eight in the workgroups of a gather that
 // rides on a cross launch, packed_cross_kernel).
-template <int TT, int MODE, int R, bool OBS, int VPT = 1, bool LUT = false, bool OBSNT = false, int WPB = 4>
+// DIGLDS (one trait): the digit planes come from a copy in LDS that the workgroup's WPB row waves make when they enter
+// -- each a share, by LDS-DMA, under the two round trips to memory every wave starts with (indices, first words) -- and
+// meet over an LDS counter before the first trip.  From memory every wave re-read the planes for its R rows: 123 MB
+// through the CUs' L1s per 16 x 256 x 10k launch, more than the observation it stores, on the path its stores take
+// (launch 21.3-21.5 -> 19.7-19.8 us on one box; with no digit loads at all it would be 18.1:
+// profiles/r04_ab_digits_lds.txt).
+template <int TT, int MODE, int R, bool OBS, int VPT = 1, bool OBSNT = false, int WPB = 4, bool DIGLDS = false>
 __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const int block, const int wave,
-                                                   RewardLds *rw = nullptr, const uint32_t *lut = nullptr) {
-  static_assert(!LUT || TT > 0, "the nibble tables serve the stream with GEBV");
+                                                   RewardLds *rw = nullptr, char *dig_lds = nullptr,
+                                                   unsigned *dig_ready = nullptr) {
+  static_assert(!DIGLDS || TT == 1, "the LDS copy holds one trait's digit planes");
   static_assert(TT >= 0 && TT <= 2, "effects are held in registers across the trip");
   static_assert(MODE == MODE_CROSS || MODE == MODE_GATHER, "packed rows: cross or gather");
   constexpr int NT = TT > 0 ? TT : 1;
@@ -267,6 +255,27 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
   double scale[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) scale[t] = TT > 0 ? p.scale[p.t0 + t] : 0.0;
+  // this wave's share of the digit copy: KB chunks wave, wave + WPB, ... (64 pieces of 16 bytes each; the last chunk's
+  // spare lanes fetch the last piece again -- the copy's LDS is whole KBs).  Asked for BEHIND the first words: a CU's
+  // memory pipeline is in order, and in front of them the 15 KB per wave kept every row's first store waiting
+  auto fill_digits = [&]() {
+    typedef __attribute__((address_space(3))) void *lds_p;
+    typedef const __attribute__((address_space(1))) void *glb_p;
+    const int npieces = 3 * (p.nvec + 1);
+    const char *g = reinterpret_cast<const char *>(p.dig);
+    for (int ch = wave; 64 * ch < npieces; ch += WPB) {
+      const int piece = 64 * ch + lane < npieces ? 64 * ch + lane : npieces - 1;
+      __builtin_amdgcn_global_load_lds((glb_p)(g + 16u * (uint32_t)piece), (lds_p)(dig_lds + 1024 * ch), 16, 0, 0);
+    }
+  };
+  if constexpr (DIGLDS) {
+    if (first >= p.n_rows) {  // a wave without rows still owes the others its share
+      fill_digits();
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      if (lane == 0) __hip_atomic_fetch_add(dig_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return;
+    }
+  }
   for (int sq = 0; sq < seq; ++sq) {
     const int c0 = first + sq * R;
     if (c0 >= p.n_rows) return;
@@ -376,42 +385,32 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
 #pragma unroll
           for (int q = 0; q < TT; ++q)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) dg[u][q][j] = *reinterpret_cast<const uint4 *>(plane[q][j] + 16u * vd);
+            for (int j = 0; j < 3; ++j) {
+              if constexpr (DIGLDS)
+                dg[u][q][j] = *reinterpret_cast<const uint4 *>(dig_lds + 16u * (uint32_t)j * (uint32_t)(p.nvec + 1) + 16u * vd);
+              else
+                dg[u][q][j] = *reinterpret_cast<const uint4 *>(plane[q][j] + 16u * vd);
+            }
         }
       }
       load_words(base + 64 * VPT * AHEAD, next);
       typedef short short2v __attribute__((ext_vector_type(2)));
       uint32_t pr[R][VPT][4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
       uint4 oo[R][VPT];
-      // every lookup of the trip is asked for before the first is used: one LDS round trip per trip, not one per vector
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int u = 0; u < VPT; ++u) {
           const int vu = v + 64 * u < last ? v + 64 * u : last;
           uint32_t o = w.a[u][r];
-          if constexpr (MODE == MODE_CROSS)
-            o = LUT ? cross16_raw(w.a[u][r], w.b[u][r], w.z[u][r]) : cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
+          if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
-          if constexpr (LUT) {
-            // byte offsets of the word's four nibbles in a table of dwords: two instructions each, shared by both tables
-            const uint32_t at[4] = {(o << 2) & 0x3cu, (o >> 2) & 0x3cu, (o >> 6) & 0x3cu, (o >> 10) & 0x3cu};
-            const char *lb = reinterpret_cast<const char *>(lut);
-            if constexpr (OBS) {
-              oo[r][u].x = *reinterpret_cast<const uint32_t *>(lb + at[0]);
-              oo[r][u].y = *reinterpret_cast<const uint32_t *>(lb + at[1]);
-              oo[r][u].z = *reinterpret_cast<const uint32_t *>(lb + at[2]);
-              oo[r][u].w = *reinterpret_cast<const uint32_t *>(lb + at[3]);
-            }
+          oo[r][u] = expand_vector(o);
+          if constexpr (TT > 0) {
+            // (a lane that redoes the row's last vector multiplies these by the zero block of the digit planes)
+            const uint32_t ww[4] = {oo[r][u].x, oo[r][u].y, oo[r][u].z, oo[r][u].w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pr[r][u][k] = *reinterpret_cast<const uint32_t *>(lb + 4 * kNibbleLutDosage + at[k]);
-          } else {
-            oo[r][u] = expand_vector(o);
-            if constexpr (TT > 0) {
-              const uint32_t ww[4] = {oo[r][u].x, oo[r][u].y, oo[r][u].z, oo[r][u].w};
-#pragma unroll
-              for (int k = 0; k < 4; ++k) pr[r][u][k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
-            }
+            for (int k = 0; k < 4; ++k) pr[r][u][k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
           }
         }
       if constexpr (OBS) {
@@ -448,7 +447,19 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
     if constexpr (AHEAD == 1) {
       Words wa, wb;
       load_words(0, wa);
+      if constexpr (DIGLDS)
+        if (sq == 0) fill_digits();
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending (row_role_pipelined)
+      if constexpr (DIGLDS) {
+        if (sq == 0) {  // this wave's share of the digit copy has landed (the wait above); the others'?
+          if (lane == 0) __hip_atomic_fetch_add(dig_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // (bounded: the waves it waits for are resident and owe nothing to this one)
+          for (int spin = 0; spin < (1 << 22) &&
+                             __hip_atomic_load(dig_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)WPB;
+               ++spin)
+            __builtin_amdgcn_s_sleep(1);
+        }
+      }
       for (int base = 0; base < p.nvec; base += 128 * VPT) {  // two trips per turn, no branch between them
         trip(base, wa, wb);
         trip(base + 64 * VPT, wb, wa);
@@ -510,12 +521,9 @@ namespace bh {
 template <int TT, int MODE, int R>
 __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   __shared__ RewardLds rwl;
-  __shared__ uint32_t nib[kNibbleLutWords];
-  constexpr bool LUT = TT > 0 && TT <= 2;  // the stream with GEBV looks its bytes and dosages up (nibble_lut_init)
   prime_next_reward(p.reward_next, p.n_envs, p.reward_pitch);
-  if (LUT || p.reward) {
+  if (p.reward) {
     if (threadIdx.x == 0) reward_lds_init(&rwl);
-    if (LUT && threadIdx.x < 16) nibble_lut_init(nib, (int)threadIdx.x);
     __syncthreads();
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep it scalar
@@ -537,11 +545,11 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
       // with GEBV in the stream: two vectors per lane and trip when the observation is written too (-2.5 % at
       // 16 x 256 x 10k), one otherwise
       if (p.outb && p.obs_nt)
-        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, true>(p, (int)blockIdx.x, wave, &rwl, nib);
+        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, true>(p, (int)blockIdx.x, wave, &rwl);
       else if (p.outb)
-        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(p, (int)blockIdx.x, wave, &rwl, nib);
+        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, false>(p, (int)blockIdx.x, wave, &rwl);
       else
-        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors, LUT>(p, (int)blockIdx.x, wave, &rwl, nib);
+        packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors>(p, (int)blockIdx.x, wave, &rwl);
       return;
     }
   }
@@ -559,8 +567,8 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
-  __shared__ uint32_t nib[kNibbleLutWords];
-  constexpr bool LUT = MW == 4 && TT > 0 && TT <= 2;  // nibble_lut_init
+  __shared__ unsigned dig_ready;  // row waves whose share of the digit copy has landed (packed_stream_role, DIGLDS)
+  constexpr bool RIDERS = MW == 4 && TT > 0 && TT <= 2;  // launches that can carry a gather asked for ahead (gp)
   int n_main = (int)gridDim.x;  // two-role workgroups
   int block = (int)blockIdx.x;  // ... and which of them this is
   bool riding = false;          // a workgroup of the gather that rides on this launch (gp)
@@ -570,14 +578,14 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     // up -- unless a gather rides too: that launch runs its workgroups in two rounds, and a draw that starts with the
     // first ends long before the second does
     const int nf = fp.out ? fp.E : 0;
-    const bool f_first = LUT && gp.n_blocks > 0;
+    const bool f_first = RIDERS && gp.n_blocks > 0;
     n_main -= nf;
     if (nf > 0 && (f_first ? block < nf : block >= n_main)) {  // uniform per workgroup
       founders_role(fp, f_first ? block : block - n_main, reinterpret_cast<uint64_t *>(lds_raw));
       return;
     }
     if (f_first) block -= nf;
-    if constexpr (LUT) {
+    if constexpr (RIDERS) {
       // gp.n_blocks > 0: a gather asked for ahead (bh_gather_packed_deferred: the founders of the reset that follows
       // this horizon step) rides on this launch as gp.n_blocks more workgroups, all eight waves of which stream
       // gathered rows (bit planes, byte observation, GEBV).  Eights of two-role workgroups and eights of riders
@@ -607,19 +615,26 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     if (threadIdx.x == 0) {
       counter = 0;
       done = 0;
+      dig_ready = 0;
       reward_lds_init(&rwl);
     }
-    if (LUT && threadIdx.x < 16) nibble_lut_init(nib, (int)threadIdx.x);
     __syncthreads();
   }
-  if constexpr (LUT) {
+  if constexpr (RIDERS) {
     if (riding) {  // all eight waves stream rows: a rider has no mask work
+      if constexpr (TT == 1) {
+        if (gp.dig_lds && gp.outb && !gp.obs_nt) {
+          packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, false, 8, true>(
+              gp, block, wave, &rwl, reinterpret_cast<char *>(lds_raw) + (gp.dig_lds - 1), &dig_ready);
+          return;
+        }
+      }
       if (gp.outb && gp.obs_nt)
-        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, true, true, 8>(gp, block, wave, &rwl, nib);
+        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, true, 8>(gp, block, wave, &rwl);
       else if (gp.outb)
-        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, true, false, 8>(gp, block, wave, &rwl, nib);
+        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, false, 8>(gp, block, wave, &rwl);
       else
-        packed_stream_role<TT, MODE_GATHER, R, false, 1, true, false, 8>(gp, block, wave, &rwl, nib);
+        packed_stream_role<TT, MODE_GATHER, R, false, 1, false, 8>(gp, block, wave, &rwl);
       return;
     }
   }
@@ -627,12 +642,19 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     if (block < rp.n_blocks) {
       if constexpr (TT <= 2 && MW == 4) {
         if (TT > 0 || rp.seq > 1) {
+          if constexpr (TT == 1) {
+            if (rp.dig_lds && rp.outb && !rp.obs_nt) {
+              packed_stream_role<TT, MODE_CROSS, R, true, kShortRowVectors, false, 4, true>(
+                  rp, block, wave, &rwl, reinterpret_cast<char *>(lds_raw) + (rp.dig_lds - 1), &dig_ready);
+              return;
+            }
+          }
           if (rp.outb && rp.obs_nt)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, true>(rp, block, wave, &rwl, nib);
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, true>(rp, block, wave, &rwl);
           else if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, LUT, false>(rp, block, wave, &rwl, nib);
+            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, false>(rp, block, wave, &rwl);
           else
-            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors, LUT>(rp, block, wave, &rwl, nib);
+            packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors>(rp, block, wave, &rwl);
           return;
         }
       }

@@ -43,7 +43,9 @@ def test_dma_stream_issues_every_store_and_dma_unconditionally(cross_isa):
     checked = []
     for name, body in kernel_bodies(cross_isa):
         dma = [i for i, l in enumerate(body) if "global_load_lds_dwordx4" in l]
-        if not dma:
+        if not dma or "packed_cross_kernel" in name:
+            # (the two-role launch of short rows uses LDS-DMA too, but only in front of its stream: the row waves' copy of
+            # the digit planes, behind a full wait -- packed_stream_role, DIGLDS; its loop's waits are the compiler's)
             continue
         obs = [i for i, l in enumerate(body) if re.search(r"global_store_dwordx4.*\bnt\b", l)]
         assert len(obs) >= 16, f"{name}: the observation stores of the stream were expected as non-temporal"
