@@ -244,6 +244,15 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
       if (int rc = allow_big_lds(c, bh::packed_cross_kernel<TT, MW, R>, lds)) return rc;
     }
   }
+  if constexpr (MW == 4 && TT >= 1 && TT <= 2) {
+    if (gp.n_blocks > 0) {
+      if (int rc = allow_big_lds(c, bh::packed_cross_kernel<TT, MW, R, true>, lds)) return rc;
+      hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R, true>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
+      return BH_OK;
+    }
+  }
   hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));

@@ -23,6 +23,9 @@ namespace bh {
 constexpr int kLongRowPrio = 2;  // priority of the row waves of the long-row stream
 constexpr int kLongRowVectors = 4;   // vectors per lane and trip in the long-row stream
 constexpr int kShortRowVectors = 2;  // ... and in the stream with GEBV
+// ... per number of traits in the stream: two traits hold twice the digit registers -- with two vectors per trip the
+// two-role kernel needs 130 VGPRs (one workgroup per CU), with one 76: 26.9 against 29.4 us per step at 16 x 256 x 10k
+template <int TT> constexpr int obs_vectors() { return TT == 0 ? kLongRowVectors : TT == 2 ? 1 : kShortRowVectors; }
 constexpr int kNoObsVectors = 1;     // ... with GEBV but without the byte observation (2: the same; 4: +6 us per launch)
 constexpr int kLongAhead = 1, kShortAhead = 1;  // trips the stream requests ahead: without / with GEBV
 
@@ -381,7 +384,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         for (int u = 0; u < VPT; ++u) {
           // a lane that redoes the row's last vector must not count it twice: it reads the zero block that ends every
           // digit plane.  Plane bases are wave-uniform, the lanes address with one 32-bit offset.
-          const uint32_t vd = v + 64 * u < p.nvec ? (uint32_t)(v + 64 * u) : (uint32_t)p.nvec;
+          const uint32_t vd = (uint32_t)(v + 64 * u < p.nvec ? v + 64 * u : p.nvec);
 #pragma unroll
           for (int q = 0; q < TT; ++q)
 #pragma unroll
@@ -395,8 +398,6 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       }
       load_words(base + 64 * VPT * AHEAD, next);
       typedef short short2v __attribute__((ext_vector_type(2)));
-      uint32_t pr[R][VPT][4];  // (dosage of marker 2k, dosage of marker 2k+1) as two int16
-      uint4 oo[R][VPT];
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -405,32 +406,21 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           uint32_t o = w.a[u][r];
           if constexpr (MODE == MODE_CROSS) o = cross16(w.a[u][r], w.b[u][r], w.z[u][r]);
           *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu) = (uint16_t)o;
-          oo[r][u] = expand_vector(o);
-          if constexpr (TT > 0) {
-            // (a lane that redoes the row's last vector multiplies these by the zero block of the digit planes)
-            const uint32_t ww[4] = {oo[r][u].x, oo[r][u].y, oo[r][u].z, oo[r][u].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pr[r][u][k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
-          }
-        }
-      if constexpr (OBS) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int u = 0; u < VPT; ++u) {
-            const int vu = v + 64 * u < last ? v + 64 * u : last;
+          const uint4 oo = expand_vector(o);
+          if constexpr (OBS) {
             // 16-byte stores through the row's buffer descriptor, so that the cache policy is an immediate the
             // compiler knows (its waits stay counted): write-through (sc1, aux 16) or non-temporal (nt, aux 2)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 dv = {oo[r][u].x, oo[r][u].y, oo[r][u].z, oo[r][u].w};
+            const u32x4 dv = {oo.x, oo.y, oo.z, oo.w};
             __builtin_amdgcn_raw_buffer_store_b128(dv, obs_rsrc[r], (int)(16u * (uint32_t)vu), 0, OBSNT ? 2 : 16);
           }
-      }
-      if constexpr (TT > 0) {
+          if constexpr (TT > 0) {
+            // (dosage of marker 2k, dosage of marker 2k+1) as two int16; a lane that redoes the row's last vector
+            // multiplies them by the zero block of the digit planes
+            const uint32_t ww[4] = {oo.x, oo.y, oo.z, oo.w};
+            uint32_t pr[4];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int u = 0; u < VPT; ++u)
+            for (int k = 0; k < 4; ++k) pr[k] = (ww[k] + (ww[k] >> 8)) & 0x00FF00FFu;
 #pragma unroll
             for (int q = 0; q < TT; ++q)
 #pragma unroll
@@ -439,10 +429,11 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
                 int a = acc[r][q][j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                  a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[r][u][k]), __builtin_bit_cast(short2v, dd[k]), a, false);
+                  a = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, pr[k]), __builtin_bit_cast(short2v, dd[k]), a, false);
                 acc[r][q][j] = a;
               }
-      }
+          }
+        }
     };
     if constexpr (AHEAD == 1) {
       Words wa, wb;
@@ -545,9 +536,9 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
       // with GEBV in the stream: two vectors per lane and trip when the observation is written too (-2.5 % at
       // 16 x 256 x 10k), one otherwise
       if (p.outb && p.obs_nt)
-        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, true>(p, (int)blockIdx.x, wave, &rwl);
+        packed_stream_role<TT, MODE, R, true, obs_vectors<TT>(), true>(p, (int)blockIdx.x, wave, &rwl);
       else if (p.outb)
-        packed_stream_role<TT, MODE, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, false>(p, (int)blockIdx.x, wave, &rwl);
+        packed_stream_role<TT, MODE, R, true, obs_vectors<TT>(), false>(p, (int)blockIdx.x, wave, &rwl);
       else
         packed_stream_role<TT, MODE, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors>(p, (int)blockIdx.x, wave, &rwl);
       return;
@@ -561,14 +552,18 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 // fp.out != null (MW = 4 only): the last fp.E workgroups of the grid draw the founders of the reset that follows
 // this step (founders_role): 12 us of LDS sorting by 16 workgroups that would otherwise be a launch of its own
 // between the horizon step and the founder gather.
-template <int TT, int MW, int R>
+// RIDE: the instance that can carry a gather asked for ahead (gp); the steps of an episode run the one that cannot --
+// fewer registers (with the riders' paths inlined the two-trait instance went from 124 to 131 VGPRs: one workgroup
+// per CU instead of two).
+template <int TT, int MW, int R, bool RIDE = false>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp,
                                                           const FoundersParams fp, const PackedParams gp) {
+  static_assert(!RIDE || (MW == 4 && TT >= 1 && TT <= 2), "a gather rides on four-wave mask groups with fused GEBV");
   extern __shared__ __align__(16) uint8_t lds_raw[];
   __shared__ unsigned counter, done;
   __shared__ RewardLds rwl;
   __shared__ unsigned dig_ready;  // row waves whose share of the digit copy has landed (packed_stream_role, DIGLDS)
-  constexpr bool RIDERS = MW == 4 && TT > 0 && TT <= 2;  // launches that can carry a gather asked for ahead (gp)
+  constexpr bool RIDERS = RIDE;
   int n_main = (int)gridDim.x;  // two-role workgroups
   int block = (int)blockIdx.x;  // ... and which of them this is
   bool riding = false;          // a workgroup of the gather that rides on this launch (gp)
@@ -630,9 +625,9 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
         }
       }
       if (gp.outb && gp.obs_nt)
-        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, true, 8>(gp, block, wave, &rwl);
+        packed_stream_role<TT, MODE_GATHER, R, true, obs_vectors<TT>(), true, 8>(gp, block, wave, &rwl);
       else if (gp.outb)
-        packed_stream_role<TT, MODE_GATHER, R, true, kShortRowVectors, false, 8>(gp, block, wave, &rwl);
+        packed_stream_role<TT, MODE_GATHER, R, true, obs_vectors<TT>(), false, 8>(gp, block, wave, &rwl);
       else
         packed_stream_role<TT, MODE_GATHER, R, false, 1, false, 8>(gp, block, wave, &rwl);
       return;
@@ -650,9 +645,9 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
             }
           }
           if (rp.outb && rp.obs_nt)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, true>(rp, block, wave, &rwl);
+            packed_stream_role<TT, MODE_CROSS, R, true, obs_vectors<TT>(), true>(rp, block, wave, &rwl);
           else if (rp.outb)
-            packed_stream_role<TT, MODE_CROSS, R, true, TT == 0 ? kLongRowVectors : kShortRowVectors, false>(rp, block, wave, &rwl);
+            packed_stream_role<TT, MODE_CROSS, R, true, obs_vectors<TT>(), false>(rp, block, wave, &rwl);
           else
             packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors>(rp, block, wave, &rwl);
           return;
