@@ -171,7 +171,20 @@ def time_cross_launches(env, actions, reps, with_gebv=True):
     E, n = env.num_envs, env._n
     gebv = eng.empty((E, n, eng.n_traits), torch.float32) if with_gebv else None
     key = np.ascontiguousarray(env.simulator.random_key.copy())
-    if env.storage == "bits":
+    ring = getattr(env, "_ring", None)
+    if env.storage == "bits" and ring is not None and len(ring.state) >= 2 and (ring.n_envs, ring.n_out) == (E, n):
+        # the env's own output blocks in the env's own pattern: generation g reads the state of slot g & 1 and writes
+        # state and observation of the other one (what a loop that keeps nothing does, engine.StepRing) -- freshly
+        # allocated blocks read 19.4 ... 21.6 us for the same launch depending on where they land.  The env is not
+        # stepped again after this (its populations are overwritten).
+        state = [ring.state[0], ring.state[1]]
+        state[0].copy_(env._prows)
+        obsb = [ring.obs_rows[0], ring.obs_rows[1]] if env.observations == "eager" else [None, None]
+
+        def launch(i):
+            eng.cross_packed(state[i & 1], E, n, actions[i % len(actions)], n, key, env._rng_mode, state[1 - (i & 1)],
+                             obsb[1 - (i & 1)], gebv)
+    elif env.storage == "bits":
         pool, outp = env._prows, eng.empty_packed(E * n)
         obs = eng.empty_population(E * n) if env.observations == "eager" else None
 
@@ -742,7 +755,7 @@ def main():
     # 2.75 M per cross + the mask rows; the reference-layout figure of SURVEY 8d (6 M per cross: two
     # 2M-byte parents read, 2M written) is reported beside it as what an API-level observer would count.
     nbytes = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, "bits", "eager")
-    traffic, traffic_source = committed_traffic("packed_cross_kernel<1,4")
+    traffic, traffic_source = committed_traffic("packed_cross_kernel<1,4,2,false>")  # (the instance without riders: DESIGN 4f)
 
     if rank == 0:
         line = {
