@@ -376,6 +376,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       for (int j = 0; j < 3; ++j) {
         plane[q][j] = reinterpret_cast<const char *>(p.dig + ((int64_t)(p.t0 + q) * 3 + j) * ((int64_t)p.nvec + 1));
       }
+    const __attribute__((address_space(3))) char *dig3 = (const __attribute__((address_space(3))) char *)dig_lds;
     auto trip = [&](int base, const Words &w, Words &next) {
       const int v = base + lane;
       uint4 dg[VPT][NT][3];
@@ -389,8 +390,13 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
           for (int q = 0; q < TT; ++q)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              if constexpr (DIGLDS)
-                dg[u][q][j] = *reinterpret_cast<const uint4 *>(dig_lds + 16u * (uint32_t)j * (uint32_t)(p.nvec + 1) + 16u * vd);
+              if constexpr (DIGLDS)  // (an LDS pointer by type, not by inference: never a flat or global load)
+              {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(
+                    dig3 + 16u * (uint32_t)j * (uint32_t)(p.nvec + 1) + 16u * vd);
+                dg[u][q][j] = make_uint4(d[0], d[1], d[2], d[3]);
+              }
               else
                 dg[u][q][j] = *reinterpret_cast<const uint4 *>(plane[q][j] + 16u * vd);
             }

@@ -66,6 +66,23 @@ def test_dma_stream_issues_every_store_and_dma_unconditionally(cross_isa):
     assert any("packed_long_kernel" in n for n in checked) and any("packed_row_kernel" in n for n in checked), checked
 
 
+def test_two_role_kernels_address_lds_and_memory_by_type(cross_isa):
+    """The row waves' LDS copy of the digit planes (packed_stream_role, DIGLDS) is read through pointers that are LDS by
+    type: no flat_* access may appear in the two-role kernels (a generic pointer the compiler could not place becomes a
+    flat load -- or, misplaced, a global one at an aperture address, which faults), and the copy is read with
+    ds_read_b128."""
+    seen = 0
+    for name, body in kernel_bodies(cross_isa):
+        if "packed_cross_kernel" not in name:
+            continue
+        flat = [l.strip() for l in body if re.match(r"\s*flat_(load|store|atomic)", l)]
+        assert not flat, f"{name}: {flat[:4]}"
+        if "packed_cross_kernelILi1ELi4E" in name:
+            assert sum("ds_read_b128" in l for l in body) >= 12, name
+            seen += 1
+    assert seen >= 2
+
+
 @pytest.fixture(scope="module")
 def gebv_isa(tmp_path_factory):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
