@@ -383,3 +383,41 @@ def test_checkpoint_resume_on_device(storage, observations, rng):
         assert np.array_equal(np.asarray(pa), np.asarray(pb)) and np.array_equal(ra, rb) and np.array_equal(ta, tb)
         assert np.array_equal(np.asarray(ia["GEBV"]), np.asarray(ib["GEBV"]))
     assert np.array_equal(a.random_key, b.random_key) and np.array_equal(a.simulator.random_key, b.simulator.random_key)
+
+
+@pytest.mark.parametrize("E,NP,NO,M,T", [
+    (24, 64, 256, 10_000, 1),   # 6144 rows x 20 KB = 123 MB of observation: beyond the Infinity-Cache policy -> non-temporal
+                                # stores, digits from memory (cross.hip, obs_store_nt)
+    (8, 300, 1024, 1200, 1),    # 1024 keyed crosses (more than 512) shared by 8 envs: four-wave mask groups and the pipelined
+                                # stream, not the one-wave form (mask_waves_for_runahead); 8192 rows: two rows per wave
+    (8, 300, 1024, 1200, 2),    # ... with two traits (one vector per lane and trip)
+    (2, 40, 700, 3001, 1),      # 700 keyed crosses for 1400 rows: more than one per row workgroup -> one-wave mask groups
+])
+def test_packed_cross_large_batches_vs_oracle(E, NP, NO, M, T, rng):
+    """The shapes on either side of this round's dispatch rules, two generations each (the second reads the masks the
+    first launch made ahead), every output against the oracle."""
+    r = (rng.random(M) * 0.03).astype(np.float32)
+    r[:: max(1, M // 7)] = 0.5
+    eff = rng.laplace(0, 3, (M, T)).astype(np.float32)
+    eng = make_engine(r, eff)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    seed = int(rng.integers(0, 2**32))
+    key_ref = co.key_from_seed(seed)
+    key = np.array(key_ref, np.uint32).copy()
+    prow = eng.pack(eng.upload_population(pool.reshape(E * NP, M, 2)))
+    n_pool = NP
+    for gen in range(2):
+        idx = rng.integers(0, n_pool, (E, NO, 2), dtype=np.int32)
+        outp, obs = eng.empty_packed(E * NO), eng.empty_population(E * NO)
+        g, rew = eng.empty((E, NO, T), torch.float32), eng.empty_reward(E)
+        eng.cross_packed(prow, E, n_pool, torch.from_numpy(idx).cuda(), NO, key, 0, outp, obs, g, rew)
+        ref, key_ref = co.cross(pool, idx, r, key_ref, 0)
+        got = eng.as_genotypes(obs, E, NO).cpu().numpy().view(np.uint8).reshape(ref.shape)
+        assert np.array_equal(got, ref), f"generation {gen}"
+        assert np.array_equal(packed_host(outp), pack_numpy(ref.reshape(E * NO, M, 2)))
+        assert np.array_equal(key, key_ref)
+        g64 = co.gebv(ref, eff, want64=True)[1]
+        assert gebv_close(g.cpu().numpy(), g64)
+        assert np.allclose(rew.cpu().numpy(), g64.max(axis=(1, 2)), rtol=GEBV_RTOL)
+        pool, prow, n_pool = ref, outp, NO
