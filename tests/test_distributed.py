@@ -166,3 +166,19 @@ def test_env_sharded_two_ranks(env_rng):
 def test_population_sharded_two_ranks(storage):
     out = _run(_pop_sharded_worker, extra=(storage,))
     assert out[0][1] == out[1][1]  # identical global top-k on every rank
+
+
+@pytest.mark.timeout(240)
+def test_env_sharded_three_ranks():
+    """An odd number of ranks: the env window of every rank is a third of one vector env of nine."""
+    out = _run(_env_sharded_worker, world=3, extra=("shared",), join_s=180)
+    assert out[0][1] == out[1][1] == out[2][1]
+    assert out[0][2] == out[1][2] == out[2][2]
+
+
+@pytest.mark.timeout(240)
+def test_population_sharded_four_ranks():
+    """Four shards (configs[3] has eight): winners from every shard, ties across shards, the speculated block size and
+    its redo -- the same assertions as with two ranks, row for row against one device's generation."""
+    out = _run(_pop_sharded_worker, world=4, extra=("bits",), join_s=180)
+    assert out[0][1] == out[1][1] == out[2][1] == out[3][1]

@@ -30,6 +30,20 @@ def test_population_sharded_two_ranks_on_one_gpu(storage):
     assert out[0][1] == out[1][1]
 
 
+@pytest.mark.timeout(600)
+def test_population_sharded_four_ranks_on_one_gpu():
+    """Four ranks (four processes on device 0, gloo): winners from every shard land in every rank's gathered buffer
+    through the device-side layout; the same assertions as with two."""
+    out = _run(_pop_sharded_worker, world=4, extra=("bits", "hip"), join_s=420)
+    assert out[0][1] == out[1][1] == out[2][1] == out[3][1]
+
+
+@pytest.mark.timeout(600)
+def test_env_sharded_three_ranks_on_one_gpu():
+    out = _run(_env_sharded_worker, world=3, extra=("shared", "hip"), join_s=420)
+    assert out[0][1] == out[1][1] == out[2][1] and out[0][2] == out[1][2] == out[2][2]
+
+
 @pytest.mark.parametrize("k,n_local,world,cap", [(1, 5, 1, 1), (9, 20, 2, 5), (9, 20, 2, 1), (819, 1024, 8, 140), (1500, 700, 3, 700),
                                                  (6553, 8192, 8, 900), (6553, 8192, 8, 50), (65536, 8192, 8, 8192),
                                                  (5000, 64, 256, 40)])
