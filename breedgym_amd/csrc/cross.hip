@@ -218,7 +218,8 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
     // have become the same kind of stream: packed rows out, its GEBV fused with this many traits, rows in twos or not
     const auto &ga = c->gather_ahead;
     const GatherPlan g = plan_gather(c, ga.src, ga.src_rows, ga.idx, ga.n_rows, ga.outp, ga.outb, ga.gebv);
-    if (g.fused && g.turns <= 1 && ga.outp && tt_for(g.p.tcount) == TT && (ga.n_rows >= 4096 ? 2 : 1) == R) {
+    if (g.fused && g.turns <= 1 && ga.outp && tt_for(g.p.tcount) == TT && (ga.n_rows >= 4096 ? 2 : 1) == R &&
+        !(rp.outb && rp.obs_nt) && !(g.p.outb && g.p.obs_nt)) {
       gp = g.p;
       gp.n_blocks = (gp.n_rows + 8 * R - 1) / (8 * R);  // all eight waves of a rider stream rows
       grid += gp.n_blocks;

@@ -630,9 +630,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
           return;
         }
       }
-      if (gp.outb && gp.obs_nt)
-        packed_stream_role<TT, MODE_GATHER, R, true, obs_vectors<TT>(), true, 8>(gp, block, wave, &rwl);
-      else if (gp.outb)
+      if (gp.outb)  // (write-through: a gather whose observation wants non-temporal stores does not ride, cross.hip)
         packed_stream_role<TT, MODE_GATHER, R, true, obs_vectors<TT>(), false, 8>(gp, block, wave, &rwl);
       else
         packed_stream_role<TT, MODE_GATHER, R, false, 1, false, 8>(gp, block, wave, &rwl);
@@ -650,9 +648,11 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
               return;
             }
           }
-          if (rp.outb && rp.obs_nt)
-            packed_stream_role<TT, MODE_CROSS, R, true, obs_vectors<TT>(), true>(rp, block, wave, &rwl);
-          else if (rp.outb)
+          if (!RIDE && rp.outb && rp.obs_nt) {
+            if constexpr (!RIDE)  // (nothing rides on a launch whose observation wants non-temporal stores: the instance
+                                  // that carries riders is the largest kernel of the library as it is)
+              packed_stream_role<TT, MODE_CROSS, R, true, obs_vectors<TT>(), true>(rp, block, wave, &rwl);
+          } else if (rp.outb)
             packed_stream_role<TT, MODE_CROSS, R, true, obs_vectors<TT>(), false>(rp, block, wave, &rwl);
           else
             packed_stream_role<TT, MODE_CROSS, R, false, TT == 0 ? kLongRowVectors : kNoObsVectors>(rp, block, wave, &rwl);
