@@ -25,8 +25,9 @@ int check_ctx(const bh_ctx *c) {
       return fail(BH_ERR_HIP, "an earlier draw (bh_founders_device / bh_selection_actions) met a bucket of more than 32768 "
                               "equal top halves among its Threefry words: its result, and every result since, is not to be trusted");
     if (w)
-      return fail(BH_ERR_HIP, "an earlier launch reported a device-side error (code %u: a mask hand-off wait ran out); "
-                              "its crossover masks, and every result since, are not to be trusted", w);
+      return fail(BH_ERR_HIP, "an earlier launch reported a device-side error (code %u: a wait among the waves of a workgroup "
+                              "ran out -- 1, 2: the mask role's hand-off; 4: the row waves' copy of the digit planes); its "
+                              "results, and every result since, are not to be trusted", w);
   }
   return BH_OK;
 }

@@ -457,6 +457,7 @@ bh::PackedParams packed_params(const bh_ctx *c) {
   p.nvp = 8 * c->nw;
   p.T = (int32_t)c->T;
   p.spare = c->d_spare;
+  p.err = c->d_err;
   return p;
 }
 

@@ -71,6 +71,7 @@ struct PackedParams {
                     // row waves of a workgroup make and read (packed_stream_role, DIGLDS); 0 = digits from memory
   int32_t obs_nt;  // how the pipelined stream stores the byte observation: 0 write-through (sc1), 1 non-temporal
                    // (obs_store_policy in cross.hip)
+  uint32_t *err;  // the context's device-side error word (host memory): a wait among a workgroup's waves that ran out
   char *spare;  // 16 KB nobody reads: where the lanes past a row's end send their stores in the LDS-DMA stream
                 // (packed_dma.h), so that every trip issues the same number of memory operations
 };
@@ -450,11 +451,17 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
       if constexpr (DIGLDS) {
         if (sq == 0) {  // this wave's share of the digit copy has landed (the wait above); the others'?
           if (lane == 0) __hip_atomic_fetch_add(dig_ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          // (bounded: the waves it waits for are resident and owe nothing to this one)
-          for (int spin = 0; spin < (1 << 22) &&
-                             __hip_atomic_load(dig_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)WPB;
-               ++spin)
+          // (bounded: the waves it waits for are resident and owe nothing to this one; a wait that runs out is
+          // reported through the context's error word, like the mask role's hand-off: check_ctx)
+          bool ok = false;
+          for (int spin = 0; spin < (1 << 22); ++spin) {
+            if (__hip_atomic_load(dig_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= (unsigned)WPB) {
+              ok = true;
+              break;
+            }
             __builtin_amdgcn_s_sleep(1);
+          }
+          if (!ok && lane == 0 && p.err) __hip_atomic_fetch_or(p.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
       for (int base = 0; base < p.nvec; base += 128 * VPT) {  // two trips per turn, no branch between them
