@@ -150,6 +150,14 @@ def time_events(launch, reps, warm=5):
 
     for i in range(warm):
         launch(i)
+    # ... and the clocks settled as in time_steps: the same untimed SETTLE_S of launches before the events (a 200-launch
+    # sample taken right behind a synchronisation read 19.4 ... 22.7 us for the same launch from run to run)
+    t_end, i = time.perf_counter() + SETTLE_S, warm
+    while time.perf_counter() < t_end:
+        launch(i)
+        i += 1
+        if i % 64 == 0:
+            torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     ev0.record()
@@ -172,18 +180,19 @@ def time_cross_launches(env, actions, reps, with_gebv=True):
     gebv = eng.empty((E, n, eng.n_traits), torch.float32) if with_gebv else None
     key = np.ascontiguousarray(env.simulator.random_key.copy())
     ring = getattr(env, "_ring", None)
-    if env.storage == "bits" and ring is not None and len(ring.state) >= 2 and (ring.n_envs, ring.n_out) == (E, n):
-        # the env's own output blocks in the env's own pattern: generation g reads the state of slot g & 1 and writes
-        # state and observation of the other one (what a loop that keeps nothing does, engine.StepRing) -- freshly
-        # allocated blocks read 19.4 ... 21.6 us for the same launch depending on where they land.  The env is not
-        # stepped again after this (its populations are overwritten).
-        state = [ring.state[0], ring.state[1]]
-        state[0].copy_(env._prows)
-        obsb = [ring.obs_rows[0], ring.obs_rows[1]] if env.observations == "eager" else [None, None]
+    if (env.storage == "bits" and with_gebv and ring is not None and len(ring.state) >= 2
+            and (ring.n_envs, ring.n_out) == (E, n) and env._prows is not None):
+        # the env's own launch path on the env's own blocks: StepRing.step (one bh_step call) into whichever slot is
+        # free, the slot just written being the next call's parents -- what a loop that keeps nothing does, without the
+        # env's bookkeeping, the reward and the resets.  (Through eng.cross_packed on freshly allocated blocks the same
+        # launch read 19.4 ... 22.7 us: that wrapper's host side is as long as the launch, and where the blocks land
+        # matters.)  The env is not stepped again after this.
+        cur = [env._prows]
+        flags = env._rng_mode | (ring.OBS if env.observations == "eager" else 0)
 
         def launch(i):
-            eng.cross_packed(state[i & 1], E, n, actions[i % len(actions)], n, key, env._rng_mode, state[1 - (i & 1)],
-                             obsb[1 - (i & 1)], gebv)
+            slot, _ = ring.step(cur[0].data_ptr(), n, actions[i % len(actions)], key, flags, False, False)
+            cur[0] = ring.state[slot]
     elif env.storage == "bits":
         pool, outp = env._prows, eng.empty_packed(E * n)
         obs = eng.empty_population(E * n) if env.observations == "eager" else None
@@ -719,7 +728,7 @@ def main():
         dt_l, _ = time_steps(env, actions, args.long_steps, 0, barrier)
         dt_long = float(all_reduce(torch.tensor([dt_l], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
     crosses_per_step = N_ENVS * N_PER_ENV
-    kern_ms = time_cross_launches(env, actions, max(20, args.steps))
+    kern_ms = time_cross_launches(env, actions, max(200, args.steps))
 
     # The same steps with an independent Threefry stream per cross (an extension: not what the
     # reference computes).  VALU-bound: 2 x 10k x 36 integer ops per cross.
@@ -730,7 +739,7 @@ def main():
         env_i.reset(seed=100)
         dt_i, _ = time_steps(env_i, actions, args.steps, args.warmup, barrier)
         ti = all_reduce(torch.tensor([dt_i], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
-        kern_ms_i = time_cross_launches(env_i, actions, max(20, args.steps))
+        kern_ms_i = time_cross_launches(env_i, actions, max(100, args.steps))
         del env_i
 
     # The other storage / observation choices of the same env, same outputs (one GPU only: extra
@@ -742,7 +751,7 @@ def main():
             env_v = make_env("shared", **kw)
             env_v.reset(seed=100)
             dt_v, _ = time_steps(env_v, actions, args.steps, args.warmup, barrier)
-            kms = time_cross_launches(env_v, actions, max(20, args.steps))
+            kms = time_cross_launches(env_v, actions, max(100, args.steps))
             nb = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, kw["storage"], kw.get("observations", "eager"))
             # requested bytes over time, NOT an HBM fraction: at this size the parents of a generation are the
             # previous launch's output and come out of the Infinity Cache (the byte layout asks for 246 MB)

@@ -242,21 +242,33 @@ int launch_pcross_tt(bh_ctx *c, bh::PackedParams rp, const bh::MaskParams &mp) {
       rp.dig_lds = (int32_t)at + 1;
       if (gp.n_blocks > 0) gp.dig_lds = rp.dig_lds;
       lds = at + dig;
-      if (int rc = allow_big_lds(c, bh::packed_cross_kernel<TT, MW, R>, lds)) return rc;
     }
   }
+  // an instance per Threefry layout (and one for riders): a kernel that carried both layouts' mask loops, the riders'
+  // paths and both store policies was 13.5 k instructions, beyond the reach of a branch (tests/test_isa.py)
+  auto go = [&](auto kernel) -> int {
+    if (int rc = allow_big_lds(c, kernel, lds)) return rc;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
+    return BH_OK;
+  };
+  const bool part = mp.layout == bh::LAYOUT_PARTITIONABLE;
+  int rc_launch;
   if constexpr (MW == 4 && TT >= 1 && TT <= 2) {
-    if (gp.n_blocks > 0) {
-      if (int rc = allow_big_lds(c, bh::packed_cross_kernel<TT, MW, R, true>, lds)) return rc;
-      hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R, true>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
-      return BH_OK;
-    }
+    if (gp.n_blocks > 0)
+      rc_launch = part ? go(bh::packed_cross_kernel<TT, MW, R, true, bh::LAYOUT_PARTITIONABLE>)
+                       : go(bh::packed_cross_kernel<TT, MW, R, true, bh::LAYOUT_ORIGINAL>);
+    else
+      rc_launch = part ? go(bh::packed_cross_kernel<TT, MW, R, false, bh::LAYOUT_PARTITIONABLE>)
+                       : go(bh::packed_cross_kernel<TT, MW, R, false, bh::LAYOUT_ORIGINAL>);
+  } else if (mp.sites) {
+    rc_launch = go(bh::packed_cross_kernel<TT, MW, R, false, -1>);
+  } else {
+    rc_launch = part ? go(bh::packed_cross_kernel<TT, MW, R, false, bh::LAYOUT_PARTITIONABLE>)
+                     : go(bh::packed_cross_kernel<TT, MW, R, false, bh::LAYOUT_ORIGINAL>);
   }
-  hipLaunchKernelGGL((bh::packed_cross_kernel<TT, MW, R>), dim3((unsigned)grid), dim3(512), lds, c->stream, rp, mp, fp, gp);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(BH_ERR_HIP, "packed_cross_kernel launch: %s", hipGetErrorString(e));
+  if (rc_launch) return rc_launch;
   if (mp.sites) return launch_mask_finish(c, mp);  // site words -> crossover masks
   return BH_OK;
 }

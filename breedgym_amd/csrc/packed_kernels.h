@@ -568,7 +568,9 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
 // RIDE: the instance that can carry a gather asked for ahead (gp); the steps of an episode run the one that cannot --
 // fewer registers (with the riders' paths inlined the two-trait instance went from 124 to 131 VGPRs: one workgroup
 // per CU instead of two).
-template <int TT, int MW, int R, bool RIDE = false>
+// LAYOUT: the Threefry counter layout of the mask role, an instance per layout (mask_role) -- or -1 for the instances
+// whose mask role draws one gamete stream per lane (mp.sites: the long-row launch of few keyed crosses).
+template <int TT, int MW, int R, bool RIDE = false, int LAYOUT = -1>
 __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp, const MaskParams mp,
                                                           const FoundersParams fp, const PackedParams gp) {
   static_assert(!RIDE || (MW == 4 && TT >= 1 && TT <= 2), "a gather rides on four-wave mask groups with fused GEBV");
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
       packed_row_role<TT, MODE_CROSS, R, MW == 4 ? 0 : 3>(rp, block, wave, &rwl);
     }
   } else if constexpr (MW == 1) {
-    if (block < mp.n_blocks) mask_role<1, SYNC_WAVE>(mp, block, wave - 4, lds_raw, nullptr);
+    if (block < mp.n_blocks) mask_role<1, SYNC_WAVE, LAYOUT>(mp, block, wave - 4, lds_raw, nullptr);
   } else {
     if (mp.sites) {  // long rows: one gamete stream per lane, site words to memory (mask_stream.h)
       mask_stream_role(mp, block * 4 + wave - 4, n_main * 4);
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
     }
     int iter = 0;  // crosses in turns when the grid is shorter than the mask work (cross_kernel)
     for (int mb = block; mb < mp.n_blocks; mb += n_main, ++iter)
-      mask_role<4, SYNC_COUNTER>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
+      mask_role<4, SYNC_COUNTER, LAYOUT>(mp, mb, wave - 4, lds_raw, &counter, iter, &done);
   }
 }
 

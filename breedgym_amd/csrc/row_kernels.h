@@ -259,9 +259,13 @@ __device__ __forceinline__ KeySched key_sched(uint32_t k0, uint32_t k1) {
 // share of the mask work, see cross_kernel): `counter` then counts arrivals over all turns, and
 // `done` (the number of finished prefix passes) keeps the other waves from overwriting site words
 // wave 0 is still reading.
-template <int WAVES, int SYNC>
+// LAYOUT: the Threefry counter layout as a compile-time fact (LAYOUT_ORIGINAL / LAYOUT_PARTITIONABLE) where the caller
+// is an instance of its own per layout -- the two-role launches of bit-plane rows, whose kernels would otherwise carry
+// both layouts' hand-placed loops and grow past what a branch reaches (packed_kernels.h) -- or -1: p.layout decides.
+template <int WAVES, int SYNC, int LAYOUT = -1>
 __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, const int wave, uint8_t *lds_raw,
                                           unsigned *counter, const int iter = 0, unsigned *done = nullptr) {
+  const bool partitionable = LAYOUT < 0 ? p.layout == LAYOUT_PARTITIONABLE : LAYOUT == LAYOUT_PARTITIONABLE;
   static_assert(WAVES == 1 || WAVES == 4, "a group is one wave or four");
   static_assert((WAVES == 1) == (SYNC == SYNC_WAVE), "one wave needs no hand-off, four need one");
   constexpr int GROUPS = 4 / WAVES;
@@ -285,7 +289,7 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
     const uint32_t cg = p.key_offset + (uint32_t)c;
     const uint32_t kidx = p.dh ? 1u + cg : 1u + 2u * cg + q;
     uint32_t rw;
-    if (p.layout == LAYOUT_PARTITIONABLE) {  // key k = TF(key, (0, k)); lanes 2q, 2q+1 both make gamete q's
+    if (partitionable) {  // key k = TF(key, (0, k)); lanes 2q, 2q+1 both make gamete q's
       const u32x2 gk = threefry2x32(p.key0, p.key1, 0u, kidx);
       const u32x2 rk = threefry2x32(gk.x, gk.y, 0u, 0u);  // split(gamete_key, 2)[0]
       rw = w ? rk.y : rk.x;
@@ -418,7 +422,7 @@ __device__ __forceinline__ void mask_role(const MaskParams &p, const int block, 
 #define BH_TLOAD(r_, v_, s_) __builtin_amdgcn_raw_buffer_load_b32(r_, v_, s_, 0)
 constexpr int kMaskNpf = 4;  // trips whose tables are requested ahead
   constexpr int NPF = kMaskNpf;
-  if (p.layout == LAYOUT_PARTITIONABLE)
+  if (partitionable)
   {
     int t = wv;
     uint32_t j = (uint32_t)wv * 64u + lane;
