@@ -86,18 +86,13 @@ def test_two_role_kernels_address_lds_and_memory_by_type(cross_isa):
 def test_two_role_kernels_stay_within_reach_of_a_branch(cross_isa):
     """The two-role kernels are large (several roles and their variants inlined, hundreds of hand-placed Threefry
     instructions per mask-role path, which LLVM sizes pessimistically), and beyond +-128 KB a branch is relaxed into
-    s_getpc_b64 / s_setpc_b64 through a scavenged SGPR pair.  The shipped instances carry at most one such long
-    branch each (to their exits); two experimental variants that added one more stream-role instance ended in a memory
-    fault at a garbage address and in an illegal instruction (profiles/r04_ab_digits_lds.txt, section 5).  This pins
-    the count so that growth is noticed here, on the CPU, and not on the GPU."""
-    worst = {}
-    for name, body in kernel_bodies(cross_isa):
-        if "packed_cross_kernel" not in name and "packed_long_kernel" not in name and "packed_row_kernel" not in name:
-            continue
-        n = sum("s_setpc_b64" in l for l in body)
-        if n:
-            worst[name] = n
-    assert all(n <= 1 for n in worst.values()), worst
+    s_getpc_b64 / s_setpc_b64 through a scavenged SGPR pair.  Kernels that carried one or two such long branches under
+    90-160 spilled SGPRs worked; two experimental variants that added one more stream-role instance to them ended in a
+    memory fault at a garbage address and in an illegal instruction (profiles/r04_ab_digits_lds.txt, section 5).  The
+    kernels are now an instance per Threefry layout and per rider-carrying, and no kernel of cross.hip has a long branch:
+    this keeps it so -- a new variant is a new INSTANCE (a template parameter chosen on the host), not a new path."""
+    long_branches = {name: n for name, body in kernel_bodies(cross_isa) if (n := sum("s_setpc_b64" in l for l in body))}
+    assert not long_branches, long_branches
 
 
 @pytest.fixture(scope="module")
