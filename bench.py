@@ -168,7 +168,7 @@ def time_events(launch, reps, warm=5):
     return ev0.elapsed_time(ev1) / reps
 
 
-def time_cross_launches(env, actions, reps, with_gebv=True):
+def time_cross_launches(env, actions, reps, with_gebv=True, own_path=True):
     """The hot-path launch alone (the fused two-role launch: streams this generation, makes the next
     one's masks), in the env's own storage layout, through the same C entry point the env uses but
     without the reward reduction and the reset.  ``with_gebv=False`` leaves the GEBV out: where it is a
@@ -180,7 +180,7 @@ def time_cross_launches(env, actions, reps, with_gebv=True):
     gebv = eng.empty((E, n, eng.n_traits), torch.float32) if with_gebv else None
     key = np.ascontiguousarray(env.simulator.random_key.copy())
     ring = getattr(env, "_ring", None)
-    if (env.storage == "bits" and with_gebv and ring is not None and len(ring.state) >= 2
+    if (own_path and env.storage == "bits" and with_gebv and ring is not None and len(ring.state) >= 2
             and (ring.n_envs, ring.n_out) == (E, n) and env._prows is not None):
         # the env's own launch path on the env's own blocks: StepRing.step (one bh_step call) into whichever slot is
         # free, the slot just written being the next call's parents -- what a loop that keeps nothing does, without the
@@ -367,8 +367,9 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
         actions = [torch.from_numpy(arng.integers(0, n, (E, n, 2), dtype=np.int32)).to(env.device) for _ in range(4)]
         env.reset(seed=7)
         dt, _ = time_steps(env, actions, steps, warmup, barrier)
-        kms_all = time_cross_launches(env, actions, max(10, steps))
-        kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False)
+        # (both through eng.cross_packed on blocks of their own: the GEBV pass is the difference of the two)
+        kms_all = time_cross_launches(env, actions, max(10, steps), own_path=False)
+        kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False, own_path=False)
         nbytes = cross_bytes(M, E * n, n, "bits", obs)
         r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
              "roofline": roofline_of("packed_long_kernel<1,8> + mask_finish4_kernel (long rows: four row waves stream rows "
@@ -764,7 +765,7 @@ def main():
     # 2.75 M per cross + the mask rows; the reference-layout figure of SURVEY 8d (6 M per cross: two
     # 2M-byte parents read, 2M written) is reported beside it as what an API-level observer would count.
     nbytes = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, "bits", "eager")
-    traffic, traffic_source = committed_traffic("packed_cross_kernel<1,4,2,false>")  # (the instance without riders: DESIGN 4f)
+    traffic, traffic_source = committed_traffic("packed_cross_kernel<1,4,2,false,")  # (the instance without riders, either layout: DESIGN 4f)
 
     if rank == 0:
         line = {
