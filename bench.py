@@ -168,11 +168,13 @@ def time_events(launch, reps, warm=5):
     return ev0.elapsed_time(ev1) / reps
 
 
-def time_cross_launches(env, actions, reps, with_gebv=True, own_path=True):
+def time_cross_launches(env, actions, reps, with_gebv=True, own_path=True, with_reward=False):
     """The hot-path launch alone (the fused two-role launch: streams this generation, makes the next
     one's masks), in the env's own storage layout, through the same C entry point the env uses but
-    without the reward reduction and the reset.  ``with_gebv=False`` leaves the GEBV out: where it is a
-    pass of its own (long rows, three traits and more) that isolates the cross launch."""
+    without the reset.  ``with_reward=True`` (the env's own path only): exactly the launch a step of an episode
+    issues -- the per-env reward noted inside the launch, the next step's reward block primed by it.
+    ``with_gebv=False`` leaves the GEBV out: where it is a pass of its own (long rows, three traits and
+    more) that isolates the cross launch."""
     import torch
 
     eng = env.simulator.engine
@@ -191,7 +193,7 @@ def time_cross_launches(env, actions, reps, with_gebv=True, own_path=True):
         flags = env._rng_mode | (ring.OBS if env.observations == "eager" else 0)
 
         def launch(i):
-            slot, _ = ring.step(cur[0].data_ptr(), n, actions[i % len(actions)], key, flags, False, False)
+            slot, _ = ring.step(cur[0].data_ptr(), n, actions[i % len(actions)], key, flags, with_reward, with_reward)
             cur[0] = ring.state[slot]
     elif env.storage == "bits":
         pool, outp = env._prows, eng.empty_packed(E * n)
@@ -208,16 +210,70 @@ def time_cross_launches(env, actions, reps, with_gebv=True, own_path=True):
     return time_events(launch, reps)
 
 
-def roofline_of(kernel, nbytes, ms, **extra):
+ROUND = "r05"  # the round whose rocprofv3 summaries under profiles/ the line is checked against (frac_from_profiles)
+
+# Every kernel a roofline object of the line names, exactly as rocprofv3 prints it (the demangled symbol without the
+# "void bh::" prefix and the argument list) -> the profile of that configuration under profiles/<ROUND>_kernel_stats_*.
+# tests/test_isa.py checks that every one of them is a symbol of the library's emitted gfx950 ISA.
+KERNELS = {
+    "headline": ("packed_cross_kernel<1, 4, 2, false, 0>", "c2"),
+    "headline_horizon": ("packed_cross_kernel<1, 4, 2, true, 0>", "c2"),
+    "c3_cross": ("packed_long_kernel<1, 8>", "c3"),
+    "c3_finish": ("mask_finish4_kernel", "c3"),
+    "c3_gebv": ("gebv_bits_kernel<1, 4>", "c3"),
+    "c5_bytes": ("gebv_bytes_kernel<2>", "c5"),
+    "c5_bits": ("gebv_bits_regs_kernel<2>", "c5"),
+}
+
+
+def norm_kernel(name):
+    """rocprofv3's kernel name -> the form of KERNELS: no return type, namespace, argument list or blanks."""
+    return name.split("(")[0].replace("void ", "").replace("bh::", "").replace(" ", "")
+
+
+def profile_avg_us(which, cfg=None):
+    """Average duration (us) and call count of kernel KERNELS[which] in the committed rocprofv3 --kernel-trace --stats
+    summary of its configuration (profiles/<ROUND>_kernel_stats_<cfg>.csv), or (None, None, file) when there is none."""
+    import csv
+
+    name, cfg0 = KERNELS[which]
+    cfg = cfg or cfg0
+    f = ROOT / "profiles" / f"{ROUND}_kernel_stats_{cfg}.csv"
+    if f.exists():
+        for row in csv.DictReader(open(f)):
+            if norm_kernel(row["Name"]) == norm_kernel(name):
+                return float(row["AverageNs"]) / 1e3, int(row["Calls"]), f"profiles/{f.name}"
+    return None, None, f"profiles/{f.name}"
+
+
+def roofline_of(which, note, nbytes, ms, binds, extra_kernels=(), profile_cfg=None, **extra):
+    """The roofline object of kernel KERNELS[which] (+ `extra_kernels` when the timed launch is a pair): `bound` is the
+    roofline the fraction is PRICED against (the contract's enum: HBM for every kernel of this path -- SURVEY 8d),
+    `binds` says what really limits the launch where that is something else."""
     achieved = nbytes / (ms * 1e-3) / 1e9
+    names = [KERNELS[w][0] for w in (which, *extra_kernels)]
     if extra.get("traffic") is not None:
         # what the counters are (MI355X_MICROARCH.md, HBM section): requests at the memory side of the L2, Infinity-Cache
-        # hits included -- an upper bound on HBM bytes, not HBM bytes; the 2 x on FETCH_SIZE is calibrated for the
-        # 16-byte-per-lane streaming reads these kernels issue (LDS-DMA and global_load alike)
-        extra.setdefault("traffic_is", "memory-side (fabric) bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits "
-                                       "are counted, so at cache-resident sizes this is an upper bound on HBM bytes")
-    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "bytes_per_launch": nbytes, "kernel_ms": ms, **extra}
+        # hits included -- an upper bound on HBM bytes, not HBM bytes
+        extra.setdefault("traffic_is", "memory-side (fabric) bytes per launch: fetch_factor x FETCH_SIZE + WRITE_SIZE (KiB); "
+                                       "Infinity-Cache hits are counted, so at cache-resident sizes this is an upper bound on HBM bytes")
+    r = {"kernel": " + ".join(names), "kernel_note": note, "bound": "hbm", "binds": binds, "achieved": achieved,
+         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "bytes_per_launch": nbytes, "kernel_ms": ms,
+         "kernel_ms_is": "HIP events on the launch stream around back-to-back launches of exactly what a step issues, "
+                         "clocks settled (time_events)"}
+    # the same bytes over the committed rocprofv3 average of the same kernel(s): what a reader recomputes from profiles/
+    us = [profile_avg_us(w, profile_cfg) for w in (which, *extra_kernels)]
+    if all(u[0] is not None for u in us):
+        tot = sum(u[0] for u in us)
+        r["frac_from_profiles"] = nbytes / (tot * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        r["profiles_avg_us"] = tot
+        r["profiles_source"] = ", ".join(f"{u[2]}: {KERNELS[w][0]} avg {u[0]:.2f} us over {u[1]} launches"
+                                         for u, w in zip(us, (which, *extra_kernels)))
+    else:
+        r["frac_from_profiles"] = None
+        r["profiles_source"] = f"no {ROUND} summary committed yet for " + ", ".join(n for n, u in zip(names, us) if u[0] is None)
+    r.update(extra)
+    return r
 
 
 _LIVE_TRAFFIC = {}  # kernel name (as rocprofv3 prints it, blanks removed) -> HBM bytes per launch, measured by this run
@@ -234,7 +290,7 @@ def traffic_child():
 
     torch.cuda.set_device(0)
     for (N, M, E, n, chrs, reps, with_gebv) in ((N_GERMPLASM, N_MARKERS, N_ENVS, N_PER_ENV, 10, 30, True),
-                                                (2048, 100_000, 4, 2048, 21, 6, False)):
+                                                (2048, 100_000, 4, 2048, 21, 8, True)):  # (+ the step's GEBV pass over the offspring)
         gm = synthetic_genetic_map(M, n_chr=chrs, n_traits=1, seed=1)
         env = VecBreedGym(num_envs=E, initial_population=synthetic_genotypes(N, M, seed=0), individual_per_gen=n,
                           num_generations=N_GENERATIONS, autoreset=True, reward_shaping=True, sync_rewards=False, genetic_map=gm)
@@ -302,8 +358,8 @@ def live_traffic(timeout=90):
             per[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
         for k, (f, nf) in per["FETCH_SIZE"].items():
             w = per["WRITE_SIZE"].get(k, (0.0, 0))[0]
-            name = k.split("(")[0].replace("void ", "").replace("bh::", "").replace(" ", "")
-            _LIVE_TRAFFIC[name] = ((fetch_factor(name) * f + w) * 1024.0, nf)
+            name = norm_kernel(k)
+            _LIVE_TRAFFIC[name] = ((fetch_factor(name) * f + w) * 1024.0, nf, f, w)
         _LIVE_NOTE = "ok"
     except Exception as e:  # a missing counter, a timeout: the committed passes remain
         _LIVE_NOTE = f"{type(e).__name__}: {e}"
@@ -313,37 +369,51 @@ def live_traffic(timeout=90):
 
 def fetch_factor(kernel_name):
     """What FETCH_SIZE has to be multiplied by.  The guide's gfx950 correction (x 2) is for wide coalesced streaming
-    reads, which the counter tallies at half their bytes.  gebv_bits_kernel's row reads are not of that shape -- eight
-    lanes take the eight 16-byte pieces of a 128-byte line in a permuted order (LDS-DMA, csrc/gebv_bits.h) -- and are
-    tallied in full: with the digit-operand DMAs removed the counter reads 59.6 MB per launch for 51.2 MB of rows,
-    with the row DMAs removed 3.9 MB for 6.4 MB of operands (profiles/r04_ab_gebv.txt, section 5).  So for that kernel
-    the counter is taken as it is (the operands' other half, 4 MB at 2048 x 100k x 8, is left out: -5 %)."""
-    return 1.0 if "gebv_bits_kernel" in kernel_name else 2.0
+    reads (16 bytes per lane, consecutive lanes consecutive addresses), which the counter tallies at half their bytes.
+    Calibrated per kernel with variants that leave one kind of read out (rows only / operands only), one box each:
+      gebv_bits_kernel<1, 4>   rows and operands by LDS-DMA, eight lanes taking the eight 16-byte pieces of a 128-byte
+                               line in a permuted order: tallied IN FULL -- rows only 59.6 MB raw for 51.2 MB, operands only
+                               3.9 MB raw for 6.4 MB (profiles/r04_ab_gebv.txt, section 5)                          -> 1
+      gebv_bits_regs_kernel<2> rows by global_load_dwordx4, eight lanes per 128-byte line of each of eight rows per
+                               instruction, operands by global_load_dwordx4 of consecutive lanes: rows only 29.9 MB raw for
+                               51.2 MB (x 1.71), operands only 3.33 MB raw for 6.4 MB (x 1.92); blended by their raw shares
+                               0.90 / 0.10 (profiles/r05_pmc_calibration.txt)                                      -> 1.73
+    Every other kernel of the line reads 16 bytes per lane from consecutive addresses (or 2-byte words of consecutive
+    lanes, small next to its stores): the guide's x 2."""
+    n = norm_kernel(kernel_name)
+    for prefix, ff in FETCH_FACTORS.items():
+        if n.startswith(norm_kernel(prefix)):
+            return ff
+    return 2.0
 
 
-def committed_traffic(kernel_prefix):
-    """PMC traffic (2 x FETCH_SIZE + WRITE_SIZE, per launch): measured by this run (live_traffic) where that worked,
-    else from the committed rocprofv3 passes under profiles/ -- a measurement of an earlier run of the same command,
-    NOT of this run.  The source is named either way."""
-    want = kernel_prefix.replace(" ", "")
-    for name, (b, n) in _LIVE_TRAFFIC.items():
-        if name.startswith(want):
-            return b, (f"measured by this run: child passes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
-                       f"(separate), mean of {n} launches of {name}, 2 x FETCH_SIZE + WRITE_SIZE in KiB")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
-        f = ROOT / "profiles" / name
-        if not f.exists():
-            continue
+FETCH_FACTORS = {"gebv_bits_kernel<": 1.0, "gebv_bits_regs_kernel<": 1.73}
+
+
+def committed_traffic(which):
+    """PMC traffic (fetch_factor x FETCH_SIZE + WRITE_SIZE, per launch) of kernel KERNELS[which]: measured by this run
+    (live_traffic) where that worked, else from the committed rocprofv3 passes of THIS round under profiles/ -- a
+    measurement of an earlier run of the same command, NOT of this run.  The kernel is matched by its exact name; a
+    kernel no committed pass knows has no traffic figure (never another kernel's, never another round's under the same
+    label).  The source is named either way."""
+    want = norm_kernel(KERNELS[which][0])
+    if want in _LIVE_TRAFFIC:
+        b, n, f, w = _LIVE_TRAFFIC[want]
+        return b, (f"measured by this run: child passes under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                   f"(separate), mean of {n} launches of {KERNELS[which][0]}: {fetch_factor(want):g} x FETCH_SIZE ({f:.0f} KiB) "
+                   f"+ WRITE_SIZE ({w:.0f} KiB)")
+    f = ROOT / "profiles" / f"{ROUND}_pmc_traffic.json"
+    why = _LIVE_NOTE or "live passes not requested"
+    if f.exists():
         try:
-            d = json.loads(f.read_text())
+            entries = json.loads(f.read_text()).get("kernels", [])
         except Exception:
-            continue
-        entries = d.get("kernels", [d])
+            entries = []
         for e in entries:
-            if str(e.get("kernel", "")).replace(" ", "").startswith(kernel_prefix.replace(" ", "")):
-                return e.get("hbm_bytes_per_launch"), (f"profiles/{name} (rocprofv3 --pmc passes of an earlier run; not measured "
-                                                       f"by this run: {_LIVE_NOTE or 'live passes not requested'})")
-    return None, "none: no committed PMC pass for this kernel"
+            if norm_kernel(str(e.get("kernel", ""))) == want:
+                return e.get("hbm_bytes_per_launch"), (f"profiles/{f.name} (rocprofv3 --pmc passes of an earlier run of the same "
+                                                       f"command; not measured by this run: {why})")
+    return None, f"none: not measured by this run ({why}) and no committed {ROUND} PMC pass names {KERNELS[which][0]}"
 
 
 def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
@@ -371,18 +441,30 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
         kms_all = time_cross_launches(env, actions, max(10, steps), own_path=False)
         kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False, own_path=False)
         nbytes = cross_bytes(M, E * n, n, "bits", obs)
+        site_bytes = 2 * 4 * n * (M // 128 + 2) * 8  # site words written by the launch and read back by the finish kernel
+        t_long, src_long = committed_traffic("c3_cross")
+        t_fin, _ = committed_traffic("c3_finish")
+        t_gebv, src_gebv = committed_traffic("c3_gebv")
+        eager = obs == "eager"  # (the PMC passes are of the eager configuration)
+        gebv_ms = kms_all - kms
         r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
-             "roofline": roofline_of("packed_long_kernel<1,8> + mask_finish4_kernel (long rows: four row waves stream rows "
-                                     "without GEBV, eight mask waves draw the next generation's sites one gamete stream "
-                                     "per lane -- 2048 keyed crosses x 100k markers of Threefry; then site words -> masks)",
-                                     nbytes + 2 * 4 * n * (M // 128 + 2) * 8, kms,  # + site words written and read back
-                                     api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
-             # both kernels of the timed pair; the PMC passes are of the eager configuration
-             "traffic": (committed_traffic("packed_long_kernel")[0] or 0) + (committed_traffic("mask_finish")[0] or 0)
-                        if obs == "eager" and committed_traffic("packed_long_kernel")[0] else None,
-             "traffic_source": committed_traffic("packed_long_kernel")[1] if obs == "eager" else None,
-             "gebv_pass_ms": kms_all - kms,
-             "gebv_pass_note": "gebv_bits_kernel<1,4> over the bit-plane offspring (0.2 GB); whoever completes a cell writes its GEBV",
+             "roofline": roofline_of(
+                 "c3_cross", "long rows: four row waves stream rows without GEBV (LDS-DMA ring), eight mask waves draw the next "
+                 "generation's sites one gamete stream per lane -- 2048 keyed crosses x 100k markers of Threefry; then site "
+                 "words -> masks (the finish kernel)", nbytes + site_bytes, kms,
+                 binds="row role at 0.94 of the achievable ~6.3 TB/s when alone (415 us); beside it the mask role's integer issue "
+                       "(JAX's bit stream: 290 M VALU wave-instructions per launch) costs ~70 us of contention",
+                 extra_kernels=("c3_finish",), profile_cfg="c3" if eager else "c3lazy",
+                 traffic=(t_long + (t_fin or 0)) if eager and t_long else None, traffic_source=src_long if eager else None,
+                 api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
+             "gebv_pass": roofline_of(
+                 "c3_gebv", "the GEBV of the step: a matrix-core pass over the bit-plane offspring the launch just wrote; whoever "
+                 "completes a cell writes its GEBV", E * n * packed_pitch(M) + M * 64, gebv_ms,
+                 binds="its rows (one column tile); ~10 us of ramp / first operands / way out around a stream at ~5 TB/s",
+                 profile_cfg="c3" if eager else "c3lazy",
+                 kernel_ms_is="difference of the timed launch sequence with and without the GEBV output (HIP events)",
+                 traffic=t_gebv if eager else None, traffic_source=src_gebv if eager else None),
+             "gebv_pass_ms": gebv_ms,
              "step_frac_of_hbm_peak": (nbytes + E * n * packed_pitch(M)) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
         if name == "eager":
             out.update(r)
@@ -412,17 +494,22 @@ def bench_c5(reps):
     return {
         "workload": "BASELINE configs[4]: GEBV of 2048 x 100k markers x 8 traits, exact int8-digit products on MFMA",
         "byte_rows": {"ms": ms_bytes, "individuals_per_s": N / (ms_bytes * 1e-3),
-                      "roofline": roofline_of("gebv_bytes_kernel<2> (bh_gebv, byte-layout rows in one pass: bit planes built in LDS, digit GEMMs on the matrix cores, 64-bit sums by atomics)", N * 2 * M + eff_bytes, ms_bytes,
-                                              traffic=committed_traffic("gebv_bytes_kernel<2")[0], traffic_source=committed_traffic("gebv_bytes_kernel<2")[1])},
+                      "roofline": roofline_of(
+                          "c5_bytes", "bh_gebv, byte-layout rows in one pass: bit planes built in LDS, digit GEMMs on the matrix "
+                          "cores, 64-bit sums by atomics", N * 2 * M + eff_bytes, ms_bytes, binds="hbm (its rows: 410 MB)",
+                          traffic=committed_traffic("c5_bytes")[0], traffic_source=committed_traffic("c5_bytes")[1])},
         "bit_planes": {"ms": ms_bits, "individuals_per_s": N / (ms_bits * 1e-3),
-                       "roofline": roofline_of("gebv_bits_kernel<2,4> (bh_gather_packed, bit-plane rows: rows and digit operands by LDS-DMA, two row tiles per operand read)",
-                                               N * packed_pitch(M) + eff_bytes, ms_bits,
-                                               traffic=committed_traffic("gebv_bits_kernel<2")[0],
-                                               traffic_source=committed_traffic("gebv_bits_kernel<2")[1],
-                                               note="51 MB of rows: not bound by its bytes.  Ramp, first operands and the way out of the K slices "
-                                                    "are ~14 of its ~29 us; the stream between runs at ~55 % of the matrix cores' rate with VALU "
-                                                    "(bits -> int8 operands), LDS and MFMA each busy more than half of it (profiles/r04_ab_gebv.txt)",
-                                               mfma_int8_Tops=2.0 * N * M * 64 / (ms_bits * 1e-3) / 1e12, mfma_int8_peak_Tops=5000.0),
+                       "roofline": roofline_of(
+                           "c5_bits", "bh_gather_packed, bit-plane rows, two column tiles: the register-staged pass -- rows as whole "
+                           "128-byte lines turned in LDS, digit operands through registers into two LDS buffers, a barrier per "
+                           "128 markers, cells completed by 64-bit atomics that carry the arrival count",
+                           N * packed_pitch(M) + eff_bytes, ms_bits,
+                           binds="neither bytes nor MFMA: ramp, first operands and the way out of the K slices are ~14 of its ~23 us; "
+                                 "the stream between runs at ~55 % of the matrix cores' rate with VALU (bits -> int8 operands), LDS "
+                                 "and MFMA each busy more than half of it (profiles/r04_ab_gebv.txt)",
+                           traffic=committed_traffic("c5_bits")[0], traffic_source=committed_traffic("c5_bits")[1],
+                           fetch_factor=fetch_factor(KERNELS["c5_bits"][0]),
+                           mfma_int8_Tops=2.0 * N * M * 64 / (ms_bits * 1e-3) / 1e12, mfma_int8_peak_Tops=5000.0),
                        "api_level_GBps": N * 2 * M / (ms_bits * 1e-3) / 1e9},
     }
 
@@ -506,7 +593,8 @@ def bench_population(args, rank, world, local_rank, use_dist, barrier, all_reduc
 def bench_c4_one_rank(steps, warmup, barrier):
     """BASELINE configs[3] as far as one GPU goes: one rank's generation (8192 x 100k shard, its own top-k), and the
     action shaping of the whole 65,536-individual population (`SelectionScores` with the reference's default
-    k = n // 10: 21.5 M diallel pairs shuffled by three rounds of radix sorts in HBM)."""
+    k = n // 10: of the 21.5 M diallel pairs only the 8,192 wanted positions are followed backwards through JAX's three
+    shuffle rounds -- csrc/shuffle_sparse.h; nothing is sorted)."""
     import torch
 
     from breedgym_amd import HipEngine
@@ -528,16 +616,28 @@ def bench_c4_one_rank(steps, warmup, barrier):
     return out
 
 
+def count_gpus():
+    """GPUs this box offers, counted by a short-lived CHILD process (torch.cuda.device_count() goes through
+    hipGetDeviceCount -> hipInit on ROCm; the child has exited before any rank starts): the launcher itself never loads
+    the HIP runtime."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                           text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else 0
+    except Exception:
+        return 0
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (this process has
     not touched the GPU and never will), wait, relay rank 0's one JSON line.  -> exit code."""
     import socket
     import subprocess
 
-    import torch  # counting devices does not initialise the GPU (no context is created)
-
     n = args.gpus
-    ndev = torch.cuda.device_count()
+    ndev = count_gpus()  # by a child that has exited: the launcher never loads the HIP runtime
     if ndev == 0:
         print("bench.py needs a GPU: breedgym_amd has no CPU fallback", file=sys.stderr)
         return 2
@@ -552,21 +652,37 @@ def self_launch(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     argv = [sys.executable, str(ROOT / "bench.py")] + [a for a in sys.argv[1:]]
+    import tempfile
+
+    rank0_out = tempfile.TemporaryFile()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_BACKEND=backend, BENCH_SELF_LAUNCHED="1",
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        # rank 0's stdout carries the line; the other ranks' goes to stderr
-        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:  # a rank that outlives rank 0 by minutes is stuck: end it (its own pid)
-            p.kill()
-            codes.append(p.wait())
+        # rank 0's stdout carries the line (to a file: nobody has to drain a pipe while the ranks are watched); the
+        # other ranks' goes to stderr
+        procs.append(subprocess.Popen(argv, env=env, stdout=rank0_out if r == 0 else sys.stderr.fileno()))
+    # watch ALL ranks: one that dies (a fault, a kill, an exception) leaves the others waiting in a collective for as
+    # long as the backend's timeout -- so the first non-zero exit ends the job: the survivors get a few seconds, then
+    # they are ended by their own pids, and the launcher exits non-zero
+    codes = [None] * n
+    failed_at = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 10.0:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()
+                    codes[r] = p.wait()
+        time.sleep(0.05)
+    rank0_out.seek(0)
+    out = rank0_out.read()
+    rank0_out.close()
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     if any(codes) or not lines:
         sys.stderr.write(out.decode())
@@ -651,6 +767,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("BENCH_TEST_KILL_RANK") == str(rank) and use_dist:
+        # tests/test_gpu_distributed.py: a rank that dies once the group is up (SIGKILL to its own pid) -- the launcher
+        # must end the job with a non-zero exit instead of waiting for the others' collective to time out
+        import signal
+
+        os.kill(os.getpid(), signal.SIGKILL)
+
     def all_reduce(t, op):  # a few numbers on the device; gloo takes them through the host
         if use_dist and backend == "nccl":
             dist.all_reduce(t, op=op)
@@ -729,7 +852,10 @@ def main():
         dt_l, _ = time_steps(env, actions, args.long_steps, 0, barrier)
         dt_long = float(all_reduce(torch.tensor([dt_l], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item())
     crosses_per_step = N_ENVS * N_PER_ENV
-    kern_ms = time_cross_launches(env, actions, max(200, args.steps))
+    # the launch a step issues (reward noted in the launch, the next reward block primed): what `roofline` prices; and
+    # the same launch without the reward, as rounds 1-4 timed it
+    kern_ms = time_cross_launches(env, actions, max(200, args.steps), with_reward=True)
+    kern_ms_noreward = time_cross_launches(env, actions, max(200, args.steps))
 
     # The same steps with an independent Threefry stream per cross (an extension: not what the
     # reference computes).  VALU-bound: 2 x 10k x 36 integer ops per cross.
@@ -765,7 +891,7 @@ def main():
     # 2.75 M per cross + the mask rows; the reference-layout figure of SURVEY 8d (6 M per cross: two
     # 2M-byte parents read, 2M written) is reported beside it as what an API-level observer would count.
     nbytes = cross_bytes(N_MARKERS, crosses_per_step, N_PER_ENV, "bits", "eager")
-    traffic, traffic_source = committed_traffic("packed_cross_kernel<1,4,2,false,")  # (the instance without riders, either layout: DESIGN 4f)
+    traffic, traffic_source = committed_traffic("headline")  # (the instance without riders: nine of an episode's ten launches)
 
     if rank == 0:
         line = {
@@ -790,9 +916,15 @@ def main():
                 "sharding": "envs across ranks, no data-path collective",
             },
             "roofline": roofline_of(
-                "packed_cross_kernel<TT=1,MW=4,R=2> (row role: bit-plane parents -> select -> byte-layout observation + "
-                "bit-plane state + GEBV + reward; mask role: next generation's Threefry)",
-                nbytes, kern_ms, traffic=traffic, traffic_source=traffic_source,
+                "headline", "row role: bit-plane parents -> select -> byte-layout observation + bit-plane state + GEBV + per-env "
+                "reward; mask role: next generation's Threefry.  Nine of an episode's ten launches; the horizon step's is " +
+                KERNELS["headline_horizon"][0] + " (no observation, + the next episode's founder gather)",
+                nbytes, kern_ms,
+                binds="not HBM: the working set (two recycled 82 MB observation blocks + 10 MB of state) lives in the 256 MB "
+                      "Infinity Cache and the launch is byte-insensitive (without the 82 MB observation: lazy_observations.kernel_ms). "
+                      "What binds is instruction issue on the CUs -- the mask role's Threefry chains beside the row streams -- plus "
+                      "the fixed chain dispatch -> indices -> first words (~5 us); the HBM fraction is kept as the stated convention",
+                traffic=traffic, traffic_source=traffic_source, kernel_ms_without_reward=kern_ms_noreward,
                 bytes_model="per cross: 2 x M/4 parents read + M/4 state written + 2M observation written; per keyed "
                             "cross: M/4 mask row read + M/4 written for the next generation",
                 api_level_GBps=6 * N_MARKERS * crosses_per_step / (kern_ms * 1e-3) / 1e9,

@@ -96,6 +96,9 @@ SIGNATURES = {
     "bh_destroy": (_int, [_vp]),
     "bh_set_stream": (_int, [_vp, _vp]),
     "bh_sync": (_int, [_vp]),
+    "bh_clear_error": (_int, [_vp, _u32p]),
+    "bh_debug_inject_error": (_int, [_vp, _c.c_uint32, _int]),
+    "bh_debug_count_dirty_cells": (_int, [_vp, _c.POINTER(_c.c_int64)]),
     "bh_release_scratch": (_int, [_vp]),
     "bh_row_pitch": (_i64, [_vp]),
     "bh_n_markers": (_i64, [_vp]),

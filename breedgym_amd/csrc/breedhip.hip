@@ -321,6 +321,53 @@ int bh_sync(bh_ctx *c) {
   return check_ctx(c);  // ... and whatever the launches that just finished had to report
 }
 
+int bh_clear_error(bh_ctx *c, uint32_t *was) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  BH_HIP(hipSetDevice(c->device));
+  const uint32_t w = c->h_err ? *static_cast<volatile uint32_t *>(c->h_err) : 0u;
+  if (was) *was = w;
+  // what was deferred is made now (its results are as untrusted as everything since the event, but nothing is left
+  // pending), then the stream is drained: no launch is in flight while the invariants are restored
+  if (int rc = flush_founders(c)) return rc;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_gsum && c->gsum_cap > 0) BH_HIP(hipMemsetAsync(c->d_gsum, 0, (size_t)c->gsum_cap, c->stream));
+  if (c->d_S && c->s_cap > 0) BH_HIP(hipMemsetAsync(c->d_S, 0, (size_t)c->s_cap, c->stream));
+  c->pf.valid = false;          // masks made ahead by a launch that may have broken
+  c->hint.valid = false;
+  c->primed_reward = nullptr;   // a reward block primed by it is primed again
+  c->primed_envs = 0;
+  BH_HIP(hipStreamSynchronize(c->stream));
+  if (c->h_err) *static_cast<volatile uint32_t *>(c->h_err) = 0u;
+  return BH_OK;
+}
+
+int bh_debug_inject_error(bh_ctx *c, uint32_t code, int dirty) {
+  if (!c) return fail(BH_ERR_BAD_ARG, "null context");
+  BH_HIP(hipSetDevice(c->device));
+  BH_HIP(hipStreamSynchronize(c->stream));
+  if (dirty) {
+    if (!c->d_gsum || c->gsum_cap < 8) return fail(BH_ERR_BAD_ARG, "bh_debug_inject_error: no GEBV pass has run yet (no cells to dirty)");
+    // every 64th cell of the final set: an arrival count and a sum nobody will complete
+    const unsigned long long junk = (3ull << 56) | 0x123456789ull;
+    for (int64_t off = 0; off + 8 <= c->gsum_cap && off < (int64_t)64 * 8 * 64; off += 64 * 8)
+      BH_HIP(hipMemcpy(static_cast<char *>(c->d_gsum) + off, &junk, sizeof junk, hipMemcpyHostToDevice));
+  }
+  if (c->h_err) *static_cast<volatile uint32_t *>(c->h_err) = code;
+  return BH_OK;
+}
+
+int bh_debug_count_dirty_cells(bh_ctx *c, int64_t *count) {
+  if (!c || !count) return fail(BH_ERR_BAD_ARG, "bh_debug_count_dirty_cells: null argument");
+  BH_HIP(hipSetDevice(c->device));
+  BH_HIP(hipStreamSynchronize(c->stream));
+  *count = 0;
+  if (!c->d_gsum || c->gsum_cap <= 0) return BH_OK;
+  std::vector<unsigned long long> cells((size_t)(c->gsum_cap / 8));
+  BH_HIP(hipMemcpy(cells.data(), c->d_gsum, cells.size() * 8, hipMemcpyDeviceToHost));
+  for (unsigned long long v : cells) *count += v != 0ull;
+  return BH_OK;
+}
+
 int bh_release_scratch(bh_ctx *c) {
   if (int rc = check_ctx(c)) return rc;
   if (int rc = flush_founders(c)) return rc;

@@ -94,9 +94,13 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
 template <typename K>
 int allow_big_lds(bh_ctx *c, K kern, size_t lds) {
   if (lds <= 64 * 1024) return BH_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+  // once per kernel instance and context: the attribute call is a driver call, and the headline launch (59 KB of digit
+  // copy on top of its mask groups' LDS) would pay it on every step of the host path
+  const void *f = reinterpret_cast<const void *>(kern);
+  if (std::find(c->big_lds_kernels.begin(), c->big_lds_kernels.end(), f) != c->big_lds_kernels.end()) return BH_OK;
+  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
   if (e != hipSuccess) return fail(BH_ERR_HIP, "hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+  c->big_lds_kernels.push_back(f);
   return BH_OK;
 }
 

@@ -125,7 +125,8 @@ struct bh_ctx {
     int64_t n_envs = 0, n_out = 0, depth = 0, n_rewards = 0, reward_pitch = 1;
     std::vector<void *> state, obs, gebv, reward;
   } ring;
-  bool big_lds_set = false;
+  bool big_lds_set = false;  // topk_chunk_kernel's dynamic-LDS limit raised (select.hip)
+  std::vector<const void *> big_lds_kernels;  // kernel instances whose dynamic-LDS limit has been raised (allow_big_lds)
   bool select_lds_set = false;
   bool sparse_lds_set = false;
   unsigned bits_lds_set = 0;  // gebv_bits_kernel instances whose dynamic LDS limit has been raised

@@ -86,6 +86,16 @@ static int gebv_out(bh_ctx *c, int64_t rows, int64_t row_groups, int64_t group_r
   return BH_OK;
 }
 
+// behind every launch of a pass that leaves through the cells: a launch the runtime refused leaves them as they were,
+// but an earlier pack of the same call may be half-way -- the cells are zeroed again behind whatever is in flight, so
+// that "all zero whenever no launch is in flight" holds for the next call whatever this one returns
+static int launched(bh_ctx *c, const char *what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return BH_OK;
+  if (c->d_gsum && c->gsum_cap > 0) (void)hipMemsetAsync(c->d_gsum, 0, (size_t)c->gsum_cap, c->stream);
+  return fail(BH_ERR_HIP, "%s launch: %s", what, hipGetErrorString(e));
+}
+
 // K slices of a pass over `row_groups` row groups: as many as fill `wgs` workgroup slots, in whole eights when there
 // are eight or more -- slice s runs on XCD s % 8 (slice_of_block), 12 slices would give four XCDs twice the work of
 // the other four (8192 x 100k x 1 from byte rows: 398 us with 12 slices, 293 us with 22)
@@ -149,9 +159,7 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
       }
       hipLaunchKernelGGL((bh::gebv_bits_kernel<1, kGebvBitsWaves>), grid, dim3(64 * waves), lds, c->stream, p);
     }
-    BH_HIP(hipGetLastError());
-    const int rc = BH_OK;
-    if (rc) return rc;
+    if (int rc = launched(c, "gebv_bits pass")) return rc;
   }
   return BH_OK;
 }
@@ -186,7 +194,7 @@ int gebv_bytes(bh_ctx *c, const uint8_t *d_pop, int64_t rows, float *d_gebv) {
       hipLaunchKernelGGL((bh::gebv_bytes_kernel<1>), grid, dim3(256), 0, c->stream, p);
     else
       hipLaunchKernelGGL((bh::gebv_bytes_kernel<2>), grid, dim3(256), 0, c->stream, p);
-    BH_HIP(hipGetLastError());
+    if (int rc = launched(c, "gebv_bytes pass")) return rc;
   }
   return BH_OK;
 }

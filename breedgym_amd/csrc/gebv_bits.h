@@ -146,7 +146,9 @@ __device__ __forceinline__ void gebv_tiles_out(const i32x16 (&acc)[F][NT], int32
       if (2 * i >= o.T) continue;  // uniform
       const int64_t cell = gsum_index(row0 + 32 * f + r, 2 * i + h);
       gsum[f][i] = old[f][i] + mine[f][i] - (unsigned long long)arrivals_of(old[f][i]) * kOne;  // the group's sum
-      if (last1[f][i]) a1[cell] = 0ull;  // nobody else comes to this cell in this launch
+      // nobody else comes to this cell in this launch; zeroed where the additions are made (device scope), not by a plain
+      // store that would sit in this XCD's L2 until the kernel ends
+      if (last1[f][i]) __hip_atomic_store(&a1[cell], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       old2[f][i] = atomicAdd(&o.acc2[cell], last1[f][i] ? gsum[f][i] + kOne : 0ull);
     }
 #pragma unroll
@@ -158,7 +160,8 @@ __device__ __forceinline__ void gebv_tiles_out(const i32x16 (&acc)[F][NT], int32
       const uint32_t before2 = arrivals_of(old2[f][i]);
       if (!last1[f][i] || before2 + 1u != (uint32_t)o.n_groups) continue;
       const long long total = (long long)(old2[f][i] + gsum[f][i] - (unsigned long long)before2 * kOne);
-      o.acc2[gsum_index(row, trait)] = 0ull;
+      // (stragglers of carrying waves may still add 0 to this cell: exactly 0, so the order does not matter)
+      __hip_atomic_store(&o.acc2[gsum_index(row, trait)], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (trait < o.T && row < o.n_rows) o.gebv[(int64_t)row * o.Tstride + o.t0 + trait] = (float)((double)total * o.scale[trait]);
     }
 }

@@ -218,35 +218,7 @@ __device__ __forceinline__ uint64_t site_word(const uint64_t *S, int g, int w, i
 // How the WAVES waves of a mask group meet between phase A and phase B.
 enum { SYNC_WAVE = 0, SYNC_BLOCK = 1, SYNC_COUNTER = 2 };
 
-// ---- Threefry-2x32-20 for two key pairs at once, hand-placed ----------------------------------
-// Measured on gfx950 (tools/tf_variants.hip, tools/tf_nops.hip): a dependent
-// v_add_u32 -> v_alignbit_b32 -> v_xor_b32 stream issues at ~13 cycles per round, and at ~9 when
-// one scalar no-op follows the add, for 2..8 waves per SIMD alike; hipcc's own stream for the
-// same arithmetic takes ~25 % longer than this one.  Operands: %0,%1 = x0,x1 of chain A,
-// %2,%3 = chain B; per chain eight scalar key words
-//   k1, k2+1, k2, k0+2, k0, k1+3, k2+4, k0+5      (k2 = k0 ^ k1 ^ 0x1BD11BDA)
-// The caller has already added (k0, k1) to the counters.
-#define BH_RA(r) "v_add_u32 %0, %0, %1\n s_nop 0\n v_alignbit_b32 %1, %1, %1, " #r "\n v_xor_b32 %1, %1, %0\n"
-#define BH_RB(r) "v_add_u32 %2, %2, %3\n s_nop 0\n v_alignbit_b32 %3, %3, %3, " #r "\n v_xor_b32 %3, %3, %2\n"
-#define BH_IA(ka, kb) "v_add_u32 %0, " ka ", %0\n s_nop 0\n v_add_u32 %1, " kb ", %1\n"
-#define BH_IB(ka, kb) "v_add_u32 %2, " ka ", %2\n s_nop 0\n v_add_u32 %3, " kb ", %3\n"
-// rotate-left by R is v_alignbit by 32 - R: {13,15,26,6} -> {19,17,6,26}; {17,29,16,24} -> {15,3,16,8}
-#define BH_TFA                                                                                          \
-  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%4", "%5") BH_RA(15) BH_RA(3) BH_RA(16) BH_RA(8) BH_IA("%6", "%7")  \
-  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%8", "%9") BH_RA(15) BH_RA(3) BH_RA(16) BH_RA(8) BH_IA("%4", "%10") \
-  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%6", "%11")
-#define BH_TFB                                                                                                  \
-  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%12", "%13") BH_RB(15) BH_RB(3) BH_RB(16) BH_RB(8) BH_IB("%14", "%15") \
-  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%16", "%17") BH_RB(15) BH_RB(3) BH_RB(16) BH_RB(8) BH_IB("%12", "%18") \
-  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%14", "%19")
-
-struct KeySched {  // the eight scalar words one chain needs
-  uint32_t w[8];
-};
-__device__ __forceinline__ KeySched key_sched(uint32_t k0, uint32_t k1) {
-  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
-  return {{k1, k2 + 1u, k2, k0 + 2u, k0, k1 + 3u, k2 + 4u, k0 + 5u}};
-}
+// (the hand-placed Threefry block BH_TFA / BH_TFB and its key schedule live in threefry.h)
 
 // `wave` = this wave's index among the four waves that play the role in this workgroup.
 // SYNC says how the group's waves hand phase A's site words to the wave that runs phase B:

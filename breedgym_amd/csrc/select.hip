@@ -156,12 +156,24 @@ struct SparseGeom {
 SparseGeom sparse_geom(int64_t segs, int64_t N, int64_t take, int layout) {
   SparseGeom g{};
   const int64_t items = bh::sparse_items(layout, (int)N);
-  const int64_t max_items = layout == bh::LAYOUT_PARTITIONABLE ? bh::kSpMaxPositions : bh::kSpMaxPositions / 2;
-  const int64_t target = std::max<int64_t>(1, 512 / std::max<int64_t>(1, segs));  // ~two rounds of workgroups on 256 CUs
+  // ONE round of workgroups on the 256 CUs (a workgroup's 128 KB of counters leave room for one per CU): every chunk
+  // is a row of 65,536 16-bit counts that sparse_hist writes, sparse_reduce reads twice and rewrites and sparse_gather
+  // reads again -- at 21.5 M elements those passes were 320 MB per round with 512 chunks (two rounds of workgroups, each
+  // within the 65,535 positions a 16-bit count cannot wrap on), more than the sweeps' own time.  Longer chunks could wrap
+  // a count only with more than 65,535 equal top halves in one of them, which sparse_hist then sees and reports
+  // (kSpErrBucket, as sparse_select does for a bucket over its limit).
+#ifdef BH_EXP_SPARSE_TARGET
+  constexpr int64_t kTargetChunks = BH_EXP_SPARSE_TARGET;
+#else
+  constexpr int64_t kTargetChunks = 256;
+#endif
+  const int64_t max_items = layout == bh::LAYOUT_PARTITIONABLE ? 4 * bh::kSpMaxPositions : 2 * bh::kSpMaxPositions;
+  const int64_t target = std::max<int64_t>(1, kTargetChunks / std::max<int64_t>(1, segs));
   g.chunk_items = (int32_t)std::min(max_items, std::max<int64_t>(2048, (items + target - 1) / target));
   g.nchunk = (int32_t)((items + g.chunk_items - 1) / g.chunk_items);
-  const int rows = (g.nchunk + 15) / 16;
-  g.reduce_batch = rows <= 1 ? 1 : rows <= 4 ? 4 : 12;
+  const int rows = (g.nchunk + 15) / 16;  // rows per wave of sparse_reduce, asked for reduce_batch at a time
+  g.reduce_batch = rows <= 1 ? 1 : rows <= 4 ? 4 : rows <= 8 ? 8 : rows <= 12 ? 12 : rows <= 16 ? 16
+                   : (round_up(rows, 16) <= round_up(rows, 12) ? 16 : 12);
   g.nchunk_pad = 16 * (int32_t)round_up(rows, g.reduce_batch);
   g.take_stride = round_up(take, 64);
   g.list_stride = round_up(N, 64);
@@ -247,6 +259,10 @@ int shuffle_front_sparse(bh_ctx *c, const uint32_t env_key[2], int64_t E_total, 
         hipLaunchKernelGGL(bh::sparse_reduce_kernel<1>, blocks, dim3(1024), 0, c->stream, p);
       else if (g.reduce_batch == 4)
         hipLaunchKernelGGL(bh::sparse_reduce_kernel<4>, blocks, dim3(1024), 0, c->stream, p);
+      else if (g.reduce_batch == 8)
+        hipLaunchKernelGGL(bh::sparse_reduce_kernel<8>, blocks, dim3(1024), 0, c->stream, p);
+      else if (g.reduce_batch == 16)
+        hipLaunchKernelGGL(bh::sparse_reduce_kernel<16>, blocks, dim3(1024), 0, c->stream, p);
       else
         hipLaunchKernelGGL(bh::sparse_reduce_kernel<12>, blocks, dim3(1024), 0, c->stream, p);
     }

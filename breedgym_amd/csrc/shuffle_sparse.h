@@ -33,7 +33,7 @@ namespace bh {
 
 constexpr int kSpBuckets = 65536;     // the top 16 bits of a round's word
 constexpr int kSpThreads = 1024;
-constexpr int kSpMaxPositions = 65535;  // per workgroup of sparse_hist / sparse_gather: a 16-bit counter holds them all
+constexpr int kSpMaxPositions = 65535;  // per workgroup of sparse_hist: up to here a 16-bit counter holds them all, whatever the words
 constexpr int kSpMaxBucket = 32768;     // elements of one bucket beyond which the call gives up (device error word):
                                         // the mean is N / 65536 <= 512; 2^15 equal top halves among Threefry words of
                                         // distinct counters do not happen
@@ -62,17 +62,39 @@ struct SparseParams {
 // The words of items [i0, i1) of a round, item by item: f(word, position).  Original layout: item i < ceil(N/2) is the
 // Threefry call on counters (i, i + h), whose two outputs are the words of positions i and i + h (odd N: the last
 // call's second counter is 0 and its second output unused); partitionable: item = position.
+// Two items per lane and turn (kSpThreads apart) through the hand-placed two-chain block of threefry.h, the round's key
+// schedule in scalar registers: these sweeps are Threefry and little else (two per round over every position of the
+// list: 21.5 M at BASELINE configs[3]'s selection).  A lane whose second item lies past the chunk redoes its first.
+// The order in which f is called does not matter to either caller (counts; slots inside a bucket).
 template <class F>
 __device__ __forceinline__ void sparse_words(uint32_t s0, uint32_t s1, int layout, int N, int i0, int i1, F f) {
+  const uint32_t k0 = __builtin_amdgcn_readfirstlane(s0), k1 = __builtin_amdgcn_readfirstlane(s1);
+  const KeySched ks = key_sched(k0, k1);
   if (layout == LAYOUT_PARTITIONABLE) {
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += kSpThreads) f(bits_word_partitionable(s0, s1, (uint32_t)i), i);
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 2 * kSpThreads) {
+      const int ib = i + kSpThreads;
+      const bool two = ib < i1;
+      uint32_t a0 = k0, a1 = (uint32_t)i + k1, b0 = k0, b1 = (uint32_t)(two ? ib : i) + k1;
+      threefry2x32_x2(ks, a0, a1, b0, b1);
+      f(a0 ^ a1, i);
+      if (two) f(b0 ^ b1, ib);
+    }
   } else {
     const int h = (N + 1) >> 1;
-    for (int i = i0 + (int)threadIdx.x; i < i1; i += kSpThreads) {
-      const bool second = i + h < N;
-      const u32x2 o = threefry2x32(s0, s1, (uint32_t)i, second ? (uint32_t)(i + h) : 0u);
-      f(o.x, i);
-      if (second) f(o.y, i + h);
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 2 * kSpThreads) {
+      const int ib = i + kSpThreads;
+      const bool two = ib < i1;
+      const int jb = two ? ib : i;
+      const bool sa = i + h < N, sb = jb + h < N;
+      uint32_t a0 = (uint32_t)i + k0, a1 = (sa ? (uint32_t)(i + h) : 0u) + k1;
+      uint32_t b0 = (uint32_t)jb + k0, b1 = (sb ? (uint32_t)(jb + h) : 0u) + k1;
+      threefry2x32_x2(ks, a0, a1, b0, b1);
+      f(a0, i);
+      if (sa) f(a1, i + h);
+      if (two) {
+        f(b0, ib);
+        if (sb) f(b1, ib + h);
+      }
     }
   }
 }
@@ -85,10 +107,23 @@ __global__ __launch_bounds__(kSpThreads) void sparse_hist_kernel(const SparsePar
   __syncthreads();
   const uint32_t s0 = p.subkeys[((int64_t)seg * p.rounds + p.round) * 2], s1 = p.subkeys[((int64_t)seg * p.rounds + p.round) * 2 + 1];
   const int items = sparse_items(p.layout, p.N), i0 = chunk * p.chunk_items, i1 = min(i0 + p.chunk_items, items);
-  sparse_words(s0, s1, p.layout, p.N, i0, i1, [&](uint32_t w, int) {
-    const uint32_t d = w >> 16;
-    atomicAdd(&sp_lds[d >> 1], 1u << (16 * (d & 1)));
-  });
+  // a workgroup of up to 65,535 positions cannot wrap a 16-bit count; a longer chunk (one round of workgroups instead of
+  // two halves every pass over the count rows: select.hip, sparse_geom) could -- only with more than 65,535 equal top
+  // halves among its words, which is the error sparse_select reports too, seen here by the counter's value before
+  if (2 * (i1 - i0) <= kSpMaxPositions || (p.layout == LAYOUT_PARTITIONABLE && i1 - i0 <= kSpMaxPositions)) {
+    sparse_words(s0, s1, p.layout, p.N, i0, i1, [&](uint32_t w, int) {
+      const uint32_t d = w >> 16;
+      atomicAdd(&sp_lds[d >> 1], 1u << (16 * (d & 1)));
+    });
+  } else {
+    bool full = false;
+    sparse_words(s0, s1, p.layout, p.N, i0, i1, [&](uint32_t w, int) {
+      const uint32_t d = w >> 16;
+      const uint32_t old = atomicAdd(&sp_lds[d >> 1], 1u << (16 * (d & 1)));
+      full |= ((old >> (16 * (d & 1))) & 0xFFFFu) == 0xFFFFu;
+    });
+    if (full) *p.err = kSpErrBucket;
+  }
   __syncthreads();
   uint4 *dst = reinterpret_cast<uint4 *>(p.partial + ((int64_t)seg * p.nchunk_pad + chunk) * kSpBuckets);
   for (int j = tid; j < kSpLdsWords / 4; j += kSpThreads) dst[j] = reinterpret_cast<const uint4 *>(sp_lds)[j];

@@ -88,6 +88,50 @@ BH_HD uint32_t bits_word_partitionable(uint32_t k0, uint32_t k1, uint32_t i) {
   return o.x ^ o.y;
 }
 
+#if defined(__HIPCC__)
+// ---- Threefry-2x32-20 for two key pairs at once, hand-placed ----------------------------------
+// Measured on gfx950 (tools/tf_variants.hip, tools/tf_nops.hip): a dependent
+// v_add_u32 -> v_alignbit_b32 -> v_xor_b32 stream issues at ~13 cycles per round, and at ~9 when
+// one scalar no-op follows the add, for 2..8 waves per SIMD alike; hipcc's own stream for the
+// same arithmetic takes ~25 % longer than this one.  Operands: %0,%1 = x0,x1 of chain A,
+// %2,%3 = chain B; per chain eight scalar key words
+//   k1, k2+1, k2, k0+2, k0, k1+3, k2+4, k0+5      (k2 = k0 ^ k1 ^ 0x1BD11BDA)
+// The caller has already added (k0, k1) to the counters.
+#define BH_RA(r) "v_add_u32 %0, %0, %1\n s_nop 0\n v_alignbit_b32 %1, %1, %1, " #r "\n v_xor_b32 %1, %1, %0\n"
+#define BH_RB(r) "v_add_u32 %2, %2, %3\n s_nop 0\n v_alignbit_b32 %3, %3, %3, " #r "\n v_xor_b32 %3, %3, %2\n"
+#define BH_IA(ka, kb) "v_add_u32 %0, " ka ", %0\n s_nop 0\n v_add_u32 %1, " kb ", %1\n"
+#define BH_IB(ka, kb) "v_add_u32 %2, " ka ", %2\n s_nop 0\n v_add_u32 %3, " kb ", %3\n"
+// rotate-left by R is v_alignbit by 32 - R: {13,15,26,6} -> {19,17,6,26}; {17,29,16,24} -> {15,3,16,8}
+#define BH_TFA                                                                                          \
+  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%4", "%5") BH_RA(15) BH_RA(3) BH_RA(16) BH_RA(8) BH_IA("%6", "%7")  \
+  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%8", "%9") BH_RA(15) BH_RA(3) BH_RA(16) BH_RA(8) BH_IA("%4", "%10") \
+  BH_RA(19) BH_RA(17) BH_RA(6) BH_RA(26) BH_IA("%6", "%11")
+#define BH_TFB                                                                                                  \
+  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%12", "%13") BH_RB(15) BH_RB(3) BH_RB(16) BH_RB(8) BH_IB("%14", "%15") \
+  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%16", "%17") BH_RB(15) BH_RB(3) BH_RB(16) BH_RB(8) BH_IB("%12", "%18") \
+  BH_RB(19) BH_RB(17) BH_RB(6) BH_RB(26) BH_IB("%14", "%19")
+
+struct KeySched {  // the eight scalar words one chain needs
+  uint32_t w[8];
+};
+__device__ __forceinline__ KeySched key_sched(uint32_t k0, uint32_t k1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  return {{k1, k2 + 1u, k2, k0 + 2u, k0, k1 + 3u, k2 + 4u, k0 + 5u}};
+}
+
+// Two Threefry-2x32-20 calls under ONE key whose schedule is wave-uniform (scalar registers): (a0, a1) and (b0, b1) hold
+// counter + (k0, k1) going in and the two output words coming out.  The draws of the shuffles (shuffle_sparse.h) run
+// this instead of the compiler's stream for threefry2x32(): ~25 % fewer cycles per call (tools/tf_variants.hip).
+__device__ __forceinline__ void threefry2x32_x2(const KeySched &k, uint32_t &a0, uint32_t &a1, uint32_t &b0, uint32_t &b1) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc sees the declaration only)
+  asm volatile(BH_TFA BH_TFB
+               : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+               : "s"(k.w[0]), "s"(k.w[1]), "s"(k.w[2]), "s"(k.w[3]), "s"(k.w[4]), "s"(k.w[5]), "s"(k.w[6]), "s"(k.w[7]),
+                 "s"(k.w[0]), "s"(k.w[1]), "s"(k.w[2]), "s"(k.w[3]), "s"(k.w[4]), "s"(k.w[5]), "s"(k.w[6]), "s"(k.w[7]));
+#endif
+}
+#endif  // __HIPCC__
+
 // integer threshold t with  uniform_f32(bits) < r  <=>  (bits >> 9) < t   (t in [0, 2^23])
 inline uint32_t threshold23(float r) {
   if (!(r > 0.0f)) return 0u;

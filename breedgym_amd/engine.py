@@ -670,6 +670,14 @@ class HipEngine(EngineBase):
     def sync(self) -> None:
         _lib.check(self._L.bh_sync(self._h))
 
+    def clear_error(self) -> int:
+        """Recover the context after a device-side error (bh_clear_error; include/breedhip.h says what is sticky and
+        what the recovery restores) -> the error word that was set (0: none).  Results of the calls between the event
+        and this one stay untrusted."""
+        was = ctypes.c_uint32(0)
+        _lib.check(self._L.bh_clear_error(self._h, ctypes.byref(was)))
+        return int(was.value)
+
     def release_scratch(self) -> None:
         """Give back the scratch the context has grown for its larger calls (bh_release_scratch)."""
         _lib.check(self._L.bh_release_scratch(self._h))

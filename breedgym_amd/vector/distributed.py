@@ -24,6 +24,7 @@ keys of the whole batch and use its own part of them, and all ranks start from t
 
 Nothing here launches kernels of its own: compute goes through the engine of the wrapped env.
 """
+import contextlib
 from typing import Optional, Tuple
 
 import numpy as np
@@ -164,6 +165,7 @@ class ShardedPopulation:
         self.n_total = self.n_local * self.world_size
         self.cap_slack = float(cap_slack)
         self._cap_hint = None  # rows per block of the winners' all-gather, guessed for the next generation
+        self._cap_k = None     # ... and the k it was guessed for
         self.redone = 0        # generations whose guess was too small
         cuda = self._store.is_cuda
         self._counts_host = torch.empty((self.world_size + 1,), dtype=torch.int32, pin_memory=cuda)
@@ -209,8 +211,13 @@ class ShardedPopulation:
     # ---- the winners' rows on every rank --------------------------------------------------------------------------
     def _counts_to_host(self, counts: torch.Tensor) -> None:
         if self._counts_ready is not None:
-            self._counts_host.copy_(counts, non_blocking=True)
-            self._counts_ready.record()
+            # the copy and its event go where the layout kernel went: the ENGINE's stream (bh_set_stream), which need
+            # not be torch's current one -- on another stream the host could read the counts before they are written
+            # and accept blocks that are too small
+            es = getattr(self.eng, "_stream", None)
+            with torch.cuda.stream(es) if es is not None else contextlib.nullcontext():
+                self._counts_host.copy_(counts, non_blocking=True)
+                self._counts_ready.record()
         else:
             self._counts_host.copy_(counts)
 
@@ -225,6 +232,8 @@ class ShardedPopulation:
 
     def _exact_cap(self, winners: torch.Tensor) -> int:
         """The exact block size, at the price of one wait for the device (first generation, and after a bad guess)."""
+        if self.world_size == 1:  # one rank owns every winner: nothing to count, nothing to wait for
+            return self._cap_bound(winners.numel())
         _, _, counts, _ = self.eng.winner_layout(winners, self.n_local, self.world_size, self.rank, 1)
         self._counts_to_host(counts)
         return max(1, self._largest_share())
@@ -270,6 +279,8 @@ class ShardedPopulation:
         scores = self.gebv()[:, 0]
         best = self.global_topk(scores, k)
         pairs = pairs_local.as_subclass(torch.Tensor).to(device=self._store.device, dtype=torch.int32).reshape(1, -1, 2).contiguous()
+        if self._cap_k != k:  # a guess made for another k says nothing about this one
+            self._cap_hint, self._cap_k = None, k
         cap = self._cap_hint if self._cap_hint is not None else self._exact_cap(best)
         key_before = key.copy()
         while True:

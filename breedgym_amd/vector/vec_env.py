@@ -126,6 +126,7 @@ class VecBreedGym(_VectorEnvBase):
         # (indices, key after the draw, bytes of the key drawn from) of the next reset's founders, made by the launch of
         # the step before the horizon (or by the horizon step's, when nothing was made by then)
         self._founders_ahead = None
+        self._key_seen = None  # the env key as the last step (or reset) left it, where a draw ahead may follow
         # (slot, what keeps it taken, key after the draw, bytes of the key drawn from): the next reset's founder
         # population, gathered by the horizon step's launch into a slot of the ring
         self._reset_ahead = None
@@ -252,7 +253,12 @@ class VecBreedGym(_VectorEnvBase):
                                               and ahead[0].numel() == E * self.individual_per_gen):
                     ahead = self._founders_ahead = None
                 if ahead is None:
-                    self._founders_ahead = self._draw_founders(deferred=True)
+                    # a step BEFORE the horizon draws ahead only when the key stood still over the step before it: a
+                    # wrapper that advances the env key every step (SelectionScores, the reference's default high-level
+                    # wrapper) would void the draw every time -- a draw riding for nothing, a second one on the horizon
+                    # launch.  With such a wrapper the draw rides on the horizon launch and reset() gathers.
+                    if done or self._key_seen == np.ascontiguousarray(self.random_key, np.uint32).tobytes():
+                        self._founders_ahead = self._draw_founders(deferred=True)
                 elif done and self._ring is not None and self._germ_prows is not None:
                     # ... and the same launch draws the founders of the reset AFTER that one (from the key that draw
                     # left): the next horizon finds them made, no step in between carries a draw
@@ -274,6 +280,8 @@ class VecBreedGym(_VectorEnvBase):
                 self._brows = ring.obs_rows[slot] if want_obs else None
                 self._populations = ring.populations[slot] if want_obs else None
                 self.step_idx += 1
+                if self.autoreset and self.step_idx + 2 >= self.num_generations:
+                    self._key_seen = np.ascontiguousarray(self.random_key, np.uint32).tobytes()  # (see the draw ahead, above)
                 infos = {"GEBV": ring.gebv[slot]}
                 if rslot is None:
                     rews = np.zeros(E)
@@ -393,6 +401,7 @@ class VecBreedGym(_VectorEnvBase):
                 and (self._ring.n_envs, self._ring.n_out) == (E, n) and self.storage == "bits"):
             # the horizon step's launch gathered this very population already (_gather_ahead)
             slot, hold, _, self.random_key, _ = made
+            self._key_seen = np.ascontiguousarray(self.random_key, np.uint32).tobytes()
             self._founders_ahead, self._founders_next = self._founders_next, None
             ring = self._ring
             self._prows, self._brows, self._populations, self._n = (ring.state[slot], ring.obs_rows[slot],
@@ -406,6 +415,7 @@ class VecBreedGym(_VectorEnvBase):
             idx, self.random_key = ahead[0], ahead[1]  # drawn by a step's launch from this same key
         else:
             idx, self.random_key = eng.founders(self.random_key, E, len(self.germplasm), n)
+        self._key_seen = np.ascontiguousarray(self.random_key, np.uint32).tobytes()
         if self.storage == "bits":
             if self._germ_prows is None:
                 self._germ_prows = eng.pack(self._germ_rows)

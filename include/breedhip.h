@@ -82,6 +82,39 @@ int bh_destroy(bh_ctx *ctx);
  * caller's race, not the library's. */
 int bh_set_stream(bh_ctx *ctx, void *hip_stream);
 int bh_sync(bh_ctx *ctx);
+/* Device-side errors are STICKY.  The kernels report what the host cannot see at launch time through one 32-bit word
+ * in host memory that every entry point that takes a context reads first; once it is non-zero every call fails with
+ * BH_ERR_HIP ("an earlier launch reported a device-side error ...") until bh_clear_error().  What sets it:
+ *   bit 0 (1)   mask role, four waves per cross taking crosses in turns: the wait for the previous cross's prefix pass
+ *               ran out (csrc/row_kernels.h, mask_role, SYNC_COUNTER, `done`)
+ *   bit 1 (2)   mask role: the prefix wave's wait for the other three waves' site words ran out (`counter`)
+ *   bit 2 (4)   row waves of a two-role workgroup: the wait for the others' share of the LDS copy of the digit planes
+ *               ran out (csrc/packed_kernels.h, packed_stream_role, DIGLDS)
+ *   0x53500001  a draw met a bucket of more than 32768 equal top halves among its Threefry words
+ *               (csrc/shuffle_sparse.h; bh_founders_device / bh_selection_actions)
+ * The three waits are bounded spins (2^22 ... 2^24 sleeps) among the waves of ONE workgroup, all of which are resident
+ * by construction, so they end; should one run out all the same, the wave sets its bit and CONTINUES on data that may
+ * be incomplete -- the launch ends (no hang), and everything it and later launches wrote is not to be trusted: masks
+ * made ahead, GEBV, rewards.  No such event has been observed; the word exists so that it could not pass unseen.
+ *
+ * bh_clear_error: recover the context instead of destroying it.  Waits for the stream, runs what was deferred
+ * (founder draws, a gather asked for ahead), then restores every invariant a broken launch may have left violated --
+ * the cells of the matrix-core GEBV passes and the site words of the long-row mask role are zeroed again ("all zero
+ * whenever no launch is in flight"), masks made ahead and a primed reward block are dropped (the next call makes its
+ * own), a pending bh_hint_next_cross is forgotten -- and clears the word.  *was (may be null) receives the word that was
+ * set (0: nothing to clear; the scrub is done all the same).  Results of the calls between the event and the clear
+ * stay untrusted: redo them.  The reference has no counterpart (a JAX error is an exception; there is no device-side
+ * state to repair). */
+int bh_clear_error(bh_ctx *ctx, uint32_t *was);
+/* TEST HOOK, not part of the path: sets the device-side error word to `code` and, if `dirty` != 0, leaves a non-zero
+ * value in a cell of the matrix-core GEBV passes -- the state a launch that died half-way would leave -- so that the
+ * recovery above can be tested (tests/test_gpu_parity.py).  Bypasses the sticky check. */
+int bh_debug_inject_error(bh_ctx *ctx, uint32_t code, int dirty);
+/* TEST HOOK: waits for the stream and counts the cells of the matrix-core GEBV passes that are not zero.  The passes
+ * keep no counters beside their cells and never clear them up front: "all zero whenever no launch is in flight" is the
+ * invariant every launch relies on (whoever completes a cell carries its sum on and leaves it zero), so after any
+ * completed call the count must be 0 -- for every trait count and ragged row count (tests/test_gpu_parity.py). */
+int bh_debug_count_dirty_cells(bh_ctx *ctx, int64_t *count);
 /* Frees the scratch buffers a context has grown for its larger calls (the draws' and top-k's sort scratch, candidate
  * lists, the GEBV passes' cells and slabs); they are allocated again on demand.  Waits for the stream first.  The
  * reference has nothing to replace here (JAX's allocator owns its temporaries); a long-lived process that made one

@@ -71,13 +71,8 @@ def test_winner_layout_kernel(k, n_local, world, cap, rng):
     assert idx is None and np.array_equal(counts.cpu().numpy(), no.winner_layout(winners, n_local, world, 0, cap)[2])
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["envs"])
-def test_bench_self_launch_two_ranks_on_one_gpu(mode):
-    """``python bench.py --gpus 2`` as the driver spells it (plain python, no launcher): the parent starts two fresh
-    child ranks before touching the GPU and relays rank 0's line.  One GPU here, so ``--oversubscribe`` (gloo): the
-    line must say what the ranks saw and that it is a rehearsal."""
-    import json
+def _bench(*args, env_extra=None, timeout=800):
+    """``python bench.py ...`` as the driver spells it: plain python, no launcher, no RANK in the environment."""
     import os
     import subprocess
     import sys
@@ -85,15 +80,60 @@ def test_bench_self_launch_two_ranks_on_one_gpu(mode):
 
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "20", "--warmup", "5",
-                        "--long-steps", "200", "--headline-only", "--mode", mode], env=env, capture_output=True, text=True,
-                       timeout=800)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(root / "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _one_line(r):
+    import json
+
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["envs", "population"])
+def test_bench_self_launch_two_ranks_on_one_gpu(mode):
+    """``python bench.py --gpus 2 [--mode population]`` as the driver spells it (plain python, no launcher): the parent
+    starts two fresh child ranks before touching the GPU and relays rank 0's line.  One GPU here, so ``--oversubscribe``
+    (gloo): the line must say what the ranks saw and that it is a REHEARSAL of the code path, not a measurement."""
+    steps = ("--steps", "20", "--warmup", "5", "--long-steps", "200") if mode == "envs" else ("--steps", "3", "--warmup", "1")
+    line = _one_line(_bench("--gpus", "2", "--oversubscribe", *steps, "--headline-only", "--mode", mode))
     d = line["distributed"]
     assert line["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["world_size"] == 2 and "gloo" in d["backend"]
     assert d["launcher"] == "bench.py self-launch" and "oversubscribed" in d
-    assert 0 < d["rank_seconds_min"] <= d["rank_seconds_max"] and line["value"] > 0 and line["value_long"] > 0
-    assert line["config"]["crosses_per_step_per_gpu"] == 4096
+    assert 0 < d["rank_seconds_min"] <= d["rank_seconds_max"] and line["value"] > 0
+    if mode == "envs":
+        assert line["value_long"] > 0 and line["config"]["crosses_per_step_per_gpu"] == 4096
+    else:  # BASELINE configs[3] as `--gpus N --mode population` runs it: 8192 x 100k per rank
+        assert line["generations_redone"] >= 0 and line["config"]["crosses_per_step_per_gpu"] == 8192
+        assert "16384 individuals" in line["config"]["workload"] and line["scaling"] == "weak"
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_five_ranks_on_one_gpu():
+    """The widest rehearsal one GPU box allows: its process guard admits six processes on the card, and this test
+    process is one of them -- so five ranks, not the eight the driver runs on an 8-GPU node.  Env-sharded, the env window
+    over 5 x 16 envs; every rank must be seen."""
+    line = _one_line(_bench("--gpus", "5", "--oversubscribe", "--headline-only", "--steps", "5", "--warmup", "2", "--long-steps", "0"))
+    d = line["distributed"]
+    assert line["n_gpus"] == 5 and d["ranks_seen"] == 5 == d["world_size"] and "oversubscribed" in d
+    assert line["value"] > 0 and "value_long" not in line
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launch_exits_nonzero_when_a_rank_is_killed():
+    """A rank that dies once the process group is up (SIGKILL: no exception, no goodbye) must end the job: the launcher
+    watches every child, ends the survivors -- who would otherwise wait in a collective for the backend's timeout -- and
+    exits non-zero without a JSON line."""
+    import time
+
+    t0 = time.monotonic()
+    r = _bench("--gpus", "2", "--oversubscribe", "--headline-only", "--steps", "5", "--warmup", "2", "--long-steps", "0",
+               env_extra={"BENCH_TEST_KILL_RANK": "1"}, timeout=500)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+    assert "rank exit codes" in r.stderr and "-9" in r.stderr, r.stderr[-1500:]
+    assert time.monotonic() - t0 < 400

@@ -635,3 +635,93 @@ def test_context_on_a_side_stream(rng):
             busy.normal_()  # keeps the DEFAULT stream busy: nothing of the context may depend on it
             one_call()
     one_call()  # back on the default stream, with the masks the side stream made ahead
+
+
+def test_clear_error_recovers_the_context(rng):
+    """include/breedhip.h: a device-side error is sticky -- every call fails until bh_clear_error, which restores the
+    invariants a broken launch may have left violated (here: cells of the matrix-core GEBV passes that are not zero, masks
+    made ahead) -- and the first results behind it equal the oracle again."""
+    from breedgym_amd import _lib
+
+    M, T, N = 2000, 8, 300  # two column tiles: the register-staged pass; cells of 300 rows x 8 traits
+    r = (rng.random(M) * 0.02).astype(np.float32)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eng = make_engine(r, eff)
+    pop = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)
+    rows = eng.upload_population(pop)
+    packed = eng.pack(rows)
+    _, g64 = co.gebv(pop, eff, want64=True)
+
+    def gebv_both():
+        g_bytes = eng.gebv(rows).cpu().numpy()
+        g_bits = eng.empty((N, T), torch.float32)
+        eng.gather_packed(packed, None, N, None, None, g_bits)
+        return g_bytes, g_bits.cpu().numpy()
+
+    for g in gebv_both():  # grows the cells, leaves them zero
+        assert gebv_close(g, g64, eff)
+    assert eng.clear_error() == 0  # nothing set: a scrub and nothing else
+    for g in gebv_both():
+        assert gebv_close(g, g64, eff)
+
+    # a cross that makes masks ahead, then the event: the word set, cells left dirty
+    E, NP, NO = 2, 9, 16
+    pool = rng.integers(0, 2, (E, NP, M, 2), dtype=np.uint8)
+    idx = rng.integers(0, NP, (E, NO, 2), dtype=np.int32)
+    got, key, _ = run_cross(eng, pool, idx, 5, 0)
+    _lib.check(eng._L.bh_debug_inject_error(eng._h, 2, 1))
+    with pytest.raises(_lib.BreedHipError, match="device-side error"):
+        eng.gebv(rows)
+    with pytest.raises(_lib.BreedHipError, match="device-side error"):
+        eng.sync()
+    assert eng.clear_error() == 2
+    assert eng.clear_error() == 0
+    for g in gebv_both():  # the dirtied cells were zeroed: sums and arrival counts start from nothing
+        assert gebv_close(g, g64, eff)
+    # the masks made ahead were dropped: the same cross again from the same key is the oracle's
+    got2, key2, g2 = run_cross(eng, pool, idx, 5, 0)
+    ref, refkey = co.cross(pool, idx, r, co.key_from_seed(5), 0)
+    assert np.array_equal(got2, ref) and np.array_equal(got, ref) and np.array_equal(key2, refkey)
+
+    # without the scrub the dirtied cells would have shown: the hook alone (word cleared by hand through a second
+    # inject of 0) must make the pass that uses those cells wrong -- which is what the recovery is for
+    _lib.check(eng._L.bh_debug_inject_error(eng._h, 0, 1))
+    g_bits = eng.empty((N, T), torch.float32)
+    eng.gather_packed(packed, None, N, None, None, g_bits)
+    assert not gebv_close(g_bits.cpu().numpy(), g64, eff), "the test hook dirtied nothing"
+    eng.clear_error()
+    for g in gebv_both():
+        assert gebv_close(g, g64, eff)
+
+
+@pytest.mark.parametrize("T", [1, 3, 5, 7, 9, 10])
+def test_gebv_passes_leave_their_cells_zero(T, rng):
+    """The matrix-core passes clear nothing up front: every launch relies on the cells being zero, and leaves them so --
+    also for trait counts that leave columns of a pack empty and row counts that leave rows of a tile empty (padding
+    lanes add to cells of their own, which must come out zero like the others)."""
+    import ctypes
+
+    M = 20000 if T == 1 else 3000  # (one trait takes the matrix-core pass only for long rows)
+    r = np.full(M, 0.01, np.float32)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eng = make_engine(r, eff)
+    dirty = ctypes.c_int64(-1)
+    for n in (33, 130, 257):  # ragged against tiles of 32 and row groups of 128
+        pop = rng.integers(0, 2, (n, M, 2), dtype=np.uint8)
+        rows = eng.upload_population(pop)
+        packed = eng.pack(rows)
+        g = eng.empty((n, T), torch.float32)
+        eng.gather_packed(packed, None, n, None, None, g)
+        _, g64 = co.gebv(pop, eff, want64=True)
+        assert gebv_close(g.cpu().numpy(), g64, eff), (T, n)
+        from breedgym_amd import _lib
+
+        _lib.check(eng._L.bh_debug_count_dirty_cells(eng._h, ctypes.byref(dirty)))
+        assert dirty.value == 0, f"T={T}, {n} rows: {dirty.value} cells of the bit-plane pass are not zero after it"
+    big = rng.integers(0, 2, ((1 << 25) // M + 41, M, 2), dtype=np.uint8)  # >= 2^25 row x markers: the one-pass byte route
+    if T >= 3 or M >= 16385:
+        gb = eng.gebv(eng.upload_population(big)).cpu().numpy()
+        _, g64 = co.gebv(big, eff, want64=True)
+        assert gebv_close(gb, g64, eff)
+        _lib.check(eng._L.bh_debug_count_dirty_cells(eng._h, ctypes.byref(dirty)))
+        assert dirty.value == 0, f"T={T}: {dirty.value} cells of the byte-row pass are not zero after it"

@@ -141,3 +141,27 @@ def test_gebv_passes_keep_their_loads_in_flight(gebv_isa):
         assert atomics and all("sc0" in body[i] for i in atomics), f"{name}: the additions must be returned atomics"
         seen.add(name)
     assert len(seen) == 4, seen  # gebv_bytes_kernel<1>, <2>, gebv_bits_kernel<1, 4>, gebv_bits_regs_kernel<2>
+
+
+def test_every_kernel_a_roofline_names_is_a_symbol_of_the_library(cross_isa, gebv_isa):
+    """bench.py's roofline objects name kernels (bench.KERNELS) and look their time and traffic up under those names in
+    profiles/.  A name that is not a kernel of the library (round 4: configs[4]'s bit-plane pass was labelled
+    gebv_bits_kernel<2,4> while gebv_bits_regs_kernel<2> ran) makes the lookups miss silently: every name must be a
+    symbol of the emitted ISA, spelled as rocprofv3 prints it."""
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    cxxfilt = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    if not Path(cxxfilt).exists():
+        pytest.skip("no c++filt / llvm-cxxfilt available")
+    mangled = [n for n, _ in kernel_bodies(cross_isa)] + [n for n, _ in kernel_bodies(gebv_isa)]
+    out = subprocess.run([cxxfilt], input="\n".join(mangled), capture_output=True, text=True, check=True).stdout
+    symbols = {bench.norm_kernel(line) for line in out.splitlines()}
+    for which, (name, cfg) in bench.KERNELS.items():
+        assert bench.norm_kernel(name) in symbols, f"bench.KERNELS[{which!r}] = {name!r} is not a kernel of libbreedhip.so"
+        assert cfg in ("c2", "c3", "c5"), cfg
+    # ... and the calibrated fetch factors are keyed by kernels that exist
+    for prefix in bench.FETCH_FACTORS:
+        assert any(s.startswith(bench.norm_kernel(prefix)) for s in symbols), prefix

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 R=$(pwd)
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -30,4 +30,6 @@ for cfg in c2 c3; do
 done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_c5 -o p -- $C5 > $OUT/fetch_c5.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_c5 -o p -- $C5 > $OUT/write_c5.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_WR \
+  --output-format csv -d $OUT/sq_c5 -o p -- $C5 > $OUT/sq_c5.log 2>&1
 echo done; find $OUT -name "*.csv" | wc -l

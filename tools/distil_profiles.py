@@ -10,7 +10,9 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+sys.path.insert(0, str(ROOT))
+import bench  # fetch_factor: one table for the line and for the committed file
 src, dst = ROOT / "gpurun_out" / f"prof_{TAG}", ROOT / "profiles"
 
 
@@ -60,17 +62,17 @@ pmc = {f"{kind}_{cfg}": counters(f"{kind}_{cfg}") for cfg in ("c2", "c3", "c5") 
 kernels = []
 for cfg in ("c2", "c3", "c5"):
     for k, d in pmc[f"fetch_{cfg}"].items():
-        if not any(t in k for t in ("packed_cross_kernel", "packed_long_kernel", "mask_finish", "gebv_bits_kernel", "gebv_bytes_kernel", "gebv_finish_kernel", "gebv_mfma_kernel")):
+        if not any(t in k for t in ("packed_cross_kernel", "packed_long_kernel", "mask_finish", "gebv_bits_kernel", "gebv_bits_regs_kernel",
+                                    "gebv_bytes_kernel", "gebv_finish_kernel", "gebv_mfma_kernel", "tail_kernel")):
             continue
         fk = d.get("FETCH_SIZE", 0.0)
         wk = pmc[f"write_{cfg}"].get(k, {}).get("WRITE_SIZE", 0.0)
-        # gebv_bits_kernel's row reads (eight lanes, the pieces of a 128-byte line permuted) are tallied in full, not at
-        # half like a wide coalesced read: bench.py fetch_factor, profiles/r04_ab_gebv.txt section 5
-        ff = 1 if "gebv_bits_kernel" in k else 2
+        # per-kernel calibration of the FETCH_SIZE correction: bench.py fetch_factor / FETCH_FACTORS
+        ff = bench.fetch_factor(k)
         kernels.append({"config": cfg, "kernel": k, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk, "fetch_factor": ff,
                         "hbm_bytes_per_launch": ff * fk * 1024 + wk * 1024, "dispatches": d.get("dispatches")})
 (dst / f"{TAG}_pmc_traffic.json").write_text(json.dumps({
-    "correction": "fetch_factor x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (MI355X_MICROARCH.md, HBM: 2 for wide coalesced reads; 1 for gebv_bits_kernel, whose row reads the counter tallies in full); separate --pmc passes; memory-side bytes: Infinity-Cache hits are counted",
+    "correction": "fetch_factor x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (MI355X_MICROARCH.md, HBM: 2 for wide coalesced reads; per-kernel calibrations in bench.py FETCH_FACTORS); separate --pmc passes; memory-side bytes: Infinity-Cache hits are counted",
     "made_by": f"tools/collect_profiles.sh {TAG} + tools/distil_profiles.py {TAG}", "kernels": kernels}, indent=1))
 for k in kernels:
     print(f"{k['config']} {k['kernel'][:50]:50s} {k['hbm_bytes_per_launch']/1e6:10.1f} MB per launch")
