@@ -162,11 +162,7 @@ SparseGeom sparse_geom(int64_t segs, int64_t N, int64_t take, int layout) {
   // within the 65,535 positions a 16-bit count cannot wrap on), more than the sweeps' own time.  Longer chunks could wrap
   // a count only with more than 65,535 equal top halves in one of them, which sparse_hist then sees and reports
   // (kSpErrBucket, as sparse_select does for a bucket over its limit).
-#ifdef BH_EXP_SPARSE_TARGET
-  constexpr int64_t kTargetChunks = BH_EXP_SPARSE_TARGET;
-#else
-  constexpr int64_t kTargetChunks = 256;
-#endif
+  constexpr int64_t kTargetChunks = 256;  // (384: 0.50 ms, 512: 0.49, 256: 0.41 at 21.5 M elements -- profiles/r05_draws.txt)
   const int64_t max_items = layout == bh::LAYOUT_PARTITIONABLE ? 4 * bh::kSpMaxPositions : 2 * bh::kSpMaxPositions;
   const int64_t target = std::max<int64_t>(1, kTargetChunks / std::max<int64_t>(1, segs));
   g.chunk_items = (int32_t)std::min(max_items, std::max<int64_t>(2048, (items + target - 1) / target));
