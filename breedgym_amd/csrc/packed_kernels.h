@@ -99,7 +99,7 @@ __device__ __forceinline__ uint32_t cross16(uint32_t p0, uint32_t p1, uint32_t z
 // One wave streams R consecutive rows (the marker effects of a trip are loaded once for all of
 // them, as in row_role); MODE_CROSS or MODE_GATHER.  The loop is deliberately plain: requesting the
 // next trips' words ahead of the current trip's stores (software pipelining) was measured -- it costs
-// registers the mask role next door needs more than the row role needs the overlap.
+// registers the mask role next door needs more than the row role needs the overlap (docs/NOTEBOOK.md 4b).
 template <int TT, int MODE, int R, int PRIO = 3>
 __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int block, const int wave,
                                                 RewardLds *rw = nullptr) {
@@ -230,7 +230,7 @@ __device__ __forceinline__ void packed_row_role(const PackedParams &p, const int
 // TT = 0: no GEBV in the stream (long rows: the matrix-core pass over the packed offspring follows,
 // gebv_bits.h).  p.seq row groups per wave, one after the other: that keeps the grid of a launch of many
 // long rows small enough to be resident at once (not a question of DRAM pages: stores run at the same rate for
-// 512 ... 8192 concurrent row streams, tools/store_streams.hip).
+// 512 ... 8192 concurrent row streams, tools/store_streams.hip, docs/NOTEBOOK.md section 4c.3).
 // WPB: waves of a workgroup that stream rows (four beside four mask waves; all eight in the workgroups of a gather that
 // rides on a cross launch, packed_cross_kernel).
 // DIGLDS (one trait): the digit planes come from a copy in LDS that the workgroup's WPB row waves make when they enter

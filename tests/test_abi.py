@@ -11,7 +11,8 @@ from breedgym_amd import _lib
 from breedgym_amd import rng as hrng
 from oracle import c_oracle as co
 
-HEADER = Path(__file__).resolve().parents[1] / "include" / "breedhip.h"
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = ROOT / "include" / "breedhip.h"
 
 
 def declared_symbols():
@@ -105,3 +106,57 @@ def test_bench_launcher_is_loud_without_a_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "needs a GPU" in r.stderr and r.stdout.strip() == ""
+
+
+def test_gymnasium_registration_path(tmp_path):
+    """breedgym_amd/__init__.py registers the reference's six ids (breedgym/__init__.py:4-34) when gymnasium imports.
+    gymnasium is not installed on any machine of this pipeline, so the branch never ran: here a stand-in package of that
+    name -- `register` keeps a table, `make` resolves "module:attr" entry points the way gymnasium does -- is put on the
+    path of a fresh interpreter, and a registered id is made and stepped through it (oracle-backed engine, CPU)."""
+    import subprocess
+    import sys
+    import textwrap
+
+    pkg = tmp_path / "gymnasium"
+    (pkg / "envs").mkdir(parents=True)
+    (pkg / "__init__.py").write_text(textwrap.dedent('''
+        import importlib
+        from .envs.registration import registry, register
+
+        def make(id, **kwargs):
+            module, attr = registry[id.split(":")[-1]].split(":")
+            return getattr(importlib.import_module(module), attr)(**kwargs)
+    '''))
+    (pkg / "envs" / "__init__.py").write_text("")
+    (pkg / "envs" / "registration.py").write_text(textwrap.dedent('''
+        registry = {}
+
+        def register(id, entry_point, **kwargs):
+            registry[id] = entry_point
+    '''))
+    prog = textwrap.dedent(f'''
+        import sys
+        sys.path[:0] = [{str(tmp_path)!r}, {str(ROOT)!r}, {str(ROOT / "tests")!r}]
+        import gymnasium as gym
+        import numpy as np
+        import breedgym_amd
+        from oracle_engine import OracleEngine
+        from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+        assert set(gym.registry) == set(breedgym_amd.REGISTRY) and len(gym.registry) == 6, gym.registry
+        gm, geno = synthetic_genetic_map(64, n_chr=2, seed=1), synthetic_genotypes(20, 64, seed=2)
+        eng = lambda: OracleEngine(gm.recombination_vec, gm.marker_effects)
+        env = gym.make("VecBreedGym", num_envs=2, initial_population=geno, genetic_map=gm, individual_per_gen=6, engine=eng())
+        pop, _ = env.reset(seed=3)
+        pop, rew, ter, tru, info = env.step(np.zeros((2, 6, 2), np.int32))
+        assert pop.shape == (2, 6, 64, 2) and len(rew) == 2
+        twin = breedgym_amd.make("VecBreedGym", num_envs=2, initial_population=geno, genetic_map=gm, individual_per_gen=6, engine=eng())
+        twin.reset(seed=3)
+        assert np.array_equal(np.asarray(twin.step(np.zeros((2, 6, 2), np.int32))[0]), np.asarray(pop))
+        for id in gym.registry:  # every entry point resolves to a class of this package
+            module, attr = gym.registry[id].split(":")
+            assert module.startswith("breedgym_amd") and isinstance(getattr(__import__(module, fromlist=[attr]), attr), type)
+        print("registered", sorted(gym.registry))
+    ''')
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "registered ['BreedGym', 'KBestBreedGym', 'PairScores', 'SelectionScores', 'SimplifiedBreedGym', 'VecBreedGym']" in r.stdout

@@ -29,6 +29,7 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 KATS = json.loads((GOLDEN / "reference_kats.json").read_text())["kats"]
 REF_DATA = Path("/root/reference/breedgym/data")
 LAYOUTS = ("original", "partitionable")
+MATCHED = {}  # engine kind -> {KAT name: [layouts whose replay reproduced the recorded reward]}
 
 
 def _inputs():
@@ -109,8 +110,12 @@ def _check(kat, engine_kind):
         got[layout] = replay(kat, np.load(genome), _map_for(kat, gmap), engine_kind, layout)
     want = np.asarray(kat["expected"], dtype=np.float64)
     ok = {lay: bool(np.allclose(v, want, rtol=kat["rtol"], atol=kat["atol"])) for lay, v in got.items()}
-    # the reference's numbers were recorded under ONE jax version, i.e. one counter layout: either pins the chain
+    # the reference's numbers were recorded under ONE jax version, i.e. one counter layout: either pins the chain --
+    # but the SAME one for all five (a mix would be a bug, not a pass): recorded per KAT, checked by the test below
     assert any(ok.values()), f"{kat['name']} ({kat['reference']}): expected {want}, got {got}"
+    matched = [lay for lay in LAYOUTS if ok[lay]]
+    MATCHED.setdefault(engine_kind, {})[kat["name"]] = matched
+    print(f"KAT {kat['name']} ({engine_kind} engine): matched under layout {' and '.join(matched)}")  # shown with -rA
 
 
 # ---- today: the fixture and the harness ---------------------------------------------------------------------------
@@ -156,3 +161,16 @@ def test_reference_kat_oracle_engine(kat):
 @pytest.mark.parametrize("kat", KATS, ids=[k["name"] for k in KATS])
 def test_reference_kat_hip_engine(kat):
     _check(kat, "hip")
+
+
+def test_reference_kats_agree_on_one_layout():
+    """Runs behind the replays above (file order).  The five rewards were recorded under one jax version: there must be
+    ONE layout every replayed KAT matched under, the same for both engines."""
+    if not MATCHED:
+        pytest.skip("parity unpinned: no KAT was replayed (blob missing)")
+    for engine_kind, per_kat in MATCHED.items():
+        common = set(LAYOUTS)
+        for name, layouts in per_kat.items():
+            common &= set(layouts)
+        assert common, f"{engine_kind} engine: the KATs do not agree on a threefry layout: {per_kat}"
+    print("reference KATs pinned under layout:", {k: sorted(set.intersection(*map(set, v.values()))) for k, v in MATCHED.items()})

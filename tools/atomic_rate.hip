@@ -1,4 +1,4 @@
-// What do scattered global atomics cost on gfx950?  (Design question behind the wanted-only shuffle, DESIGN.md 4e: a
+// What do scattered global atomics cost on gfx950?  (Design question behind the wanted-only shuffle, docs/NOTEBOOK.md 4e: a
 // histogram of 21.5 M Threefry words into 2^16 ... 2^18 bins, and appends of ~2.7 M elements to 8192 lists.)
 //   hist   : N non-returning atomicAdd(u32) to `bins` random counters
 //   append : N returning atomicAdd(u32) to `bins` random counters, the result used (a store at the slot)
