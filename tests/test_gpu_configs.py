@@ -883,3 +883,48 @@ def test_reset_made_ahead_is_dropped_when_the_key_or_the_seed_changes():
     f, env_key = co.founders(co.key_from_seed(77), E, N, n)
     assert np.array_equal(u8(pop), geno.view(np.uint8)[f])
     assert np.array_equal(env.random_key, env_key)
+
+
+def test_reset_with_a_new_population_size_crosses_everything_made_ahead():
+    """The reference's ``reset(options={"individual_per_gen": n})`` (vec_env.py:118-119) in the middle of an episode, one
+    step before a horizon -- when the founders of the next reset are drawn ahead for the OLD size, and again right
+    behind a horizon step whose launch gathered the next episode's founders ahead: both must be dropped (sizes differ),
+    and everything after follows the oracle's chain at the new size, through its own horizons."""
+    from breedgym_amd import VecBreedGym
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    E, n0, M, N, G = 4, 32, 800, 40, 3
+    gm = synthetic_genetic_map(M, n_chr=2, n_traits=1, seed=4)
+    geno = synthetic_genotypes(N, M, seed=6)
+    env = VecBreedGym(num_envs=E, initial_population=geno, individual_per_gen=n0, num_generations=G, reward_shaping=True,
+                      genetic_map=gm)
+    env.reset(seed=5)
+    f, env_key = co.founders(co.key_from_seed(5), E, N, n0)
+    ref, sim_key = geno.view(np.uint8)[f], co.key_from_seed(5)
+    arng = np.random.default_rng(8)
+
+    def steps(k, n):
+        nonlocal ref, sim_key, env_key
+        for _ in range(k):
+            a = arng.integers(0, n, (E, n, 2), dtype=np.int32)
+            pop, rews, ter, tru, info = env.step(a)
+            ref, sim_key = co.cross(ref, a, gm.recombination_vec, sim_key, 0)
+            g = co.gebv(ref, gm.marker_effects)
+            assert np.allclose(np.asarray(info["GEBV"]), g, rtol=1e-5, atol=1e-5)
+            if env.step_idx == 0:  # the horizon: the observation is the next episode's founders
+                f, env_key = co.founders(env_key, E, N, n)
+                ref = geno.view(np.uint8)[f]
+            assert np.array_equal(u8(pop), ref) and np.array_equal(env.random_key, env_key)
+
+    steps(G - 1, n0)  # one step before the horizon: the founders of the next reset are drawn (for 32 per env)
+    assert env._founders_ahead is not None and env._founders_ahead[0].numel() == E * n0
+    for n in (24, 40):  # smaller, then larger than what was made ahead
+        pop, info = env.reset(options={"individual_per_gen": n})
+        f, env_key = co.founders(env_key, E, N, n)
+        ref = geno.view(np.uint8)[f]
+        assert pop.shape == (E, n, M, 2) and np.array_equal(u8(pop), ref) and np.array_equal(env.random_key, env_key)
+        assert np.allclose(np.asarray(info["GEBV"]), co.gebv(ref, gm.marker_effects), rtol=1e-5, atol=1e-5)
+        steps(2 * G + 1, n)  # two horizons at the new size (their founders made ahead again) and one step more
+        assert env.step_idx == 1
+        steps(G - 1, n)      # ... to right behind the next horizon: its launch gathered founders ahead, now for `n`
+        assert env.step_idx == 0
