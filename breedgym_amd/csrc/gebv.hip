@@ -127,7 +127,11 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
     const bool regs = nt == 2;
     const int waves = kGebvBitsWaves;
     const int64_t group_rows = regs ? 128 : bh::bits_rows(waves), row_groups = (rows + group_rows - 1) / group_rows;
+#ifdef BH_EXP_REGS_WGS
+    const int64_t wgs = regs ? BH_EXP_REGS_WGS : kGebvBitsWgs * (8 / waves);
+#else
     const int64_t wgs = regs ? 512 : kGebvBitsWgs * (8 / waves);  // eight waves per CU
+#endif
     // as many slices as there are workgroup slots, in whole eights (slice s runs on XCD s % 8)
     int64_t slices;
     if (regs) {
