@@ -563,6 +563,21 @@ GatherPlan plan_gather(const bh_ctx *c, const uint16_t *d_src, int64_t src_rows,
 int run_gather(bh_ctx *c, const GatherPlan &g, const uint16_t *d_src, int64_t src_rows, const int32_t *d_idx,
                int64_t n_rows, float *d_gebv) {
   const bh::PackedParams &p = g.p;
+  if (p.outp && !p.outb && !d_gebv && n_rows <= 65535 && g.turns <= 1) {
+    // bit planes out and nothing else (the winners' rows of a population-sharded generation): plain copies, a row cut
+    // over as many waves as it has 4 KB pieces (packed_copy_rows_kernel)
+    bh::CopyRowsParams q{};
+    q.src = reinterpret_cast<const uint8_t *>(d_src);
+    q.dst = reinterpret_cast<uint8_t *>(p.outp);
+    q.idx = d_idx;
+    q.row_bytes = (int64_t)16 * c->nw;
+    q.n_pool = (int32_t)src_rows;
+    q.n_rows = (int32_t)n_rows;
+    hipLaunchKernelGGL(bh::packed_copy_rows_kernel, dim3((unsigned)((q.row_bytes / 16 + 1023) / 1024), (unsigned)n_rows), dim3(256), 0,
+                       c->stream, q);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+  }
   if (p.tcount > 0 || p.outp || p.outb) {
     if (int rc = g.turns > 1 ? launch_prow_r<bh::MODE_GATHER, kRowsPerWaveLong>(c, p, 0)
                              : launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount)))

@@ -704,6 +704,34 @@ __global__ __launch_bounds__(64 * (4 + MASK_WAVES)) void packed_long_kernel(cons
   }
 }
 
+// packed rows -> packed rows through an index, nothing else (no observation, no GEBV): what the population-sharded
+// generation does with its winners before the all-gather (vector/distributed.py: a few hundred rows of 25 KB at
+// configs[3]).  The row roles above give a whole row to one wave (196 dependent trips of 2-byte words per lane for a
+// 100k-marker row: 67 us for 940 rows); here a wave takes 4 KB of a row, 16 bytes per lane, four loads in flight:
+// grid (ceil(row bytes / 4096 / 4), rows).
+struct CopyRowsParams {
+  const uint8_t *src;  // (n_pool, row_bytes) packed rows
+  uint8_t *dst;        // (n_rows, row_bytes)
+  const int32_t *idx;  // (n_rows) source row of every output row (JAX retrieval indexing), or null (= identity)
+  int64_t row_bytes;   // 16 * nw
+  int32_t n_pool, n_rows;
+};
+__global__ __launch_bounds__(256) void packed_copy_rows_kernel(const CopyRowsParams p) {
+  const int row = blockIdx.y, lane = threadIdx.x & 63;
+  const int64_t piece0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 256 + lane;  // 16-byte pieces: 256 per wave
+  const int64_t n_pieces = p.row_bytes >> 4;
+  if (piece0 - lane >= n_pieces) return;
+  const int i0 = p.idx ? norm_index(p.idx[row], p.n_pool) : row;
+  const uint4 *s = reinterpret_cast<const uint4 *>(p.src + (int64_t)i0 * p.row_bytes);
+  uint4 *d = reinterpret_cast<uint4 *>(p.dst + (int64_t)row * p.row_bytes);
+  uint4 t[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) t[u] = piece0 + 64 * u < n_pieces ? s[piece0 + 64 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (piece0 + 64 * u < n_pieces) d[piece0 + 64 * u] = t[u];
+}
+
 // byte-layout rows -> packed rows.  One lane per 16-byte vector.
 struct PackParams {
   const uint8_t *src;  // (rows, pitch)

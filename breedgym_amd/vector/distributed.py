@@ -167,6 +167,7 @@ class ShardedPopulation:
         self._cap_hint = None  # rows per block of the winners' all-gather, guessed for the next generation
         self._cap_k = None     # ... and the k it was guessed for
         self.redone = 0        # generations whose guess was too small
+        self._gebv_of_store = None  # (n_local, T) the GEBV of `_store` where the cross that wrote it took it
         cuda = self._store.is_cuda
         self._counts_host = torch.empty((self.world_size + 1,), dtype=torch.int32, pin_memory=cuda)
         self._counts_ready = torch.cuda.Event() if cuda else None
@@ -186,6 +187,10 @@ class ShardedPopulation:
             self.eng.gather(src, idx, out)
 
     def gebv(self) -> torch.Tensor:
+        # the GEBV of the shard as the cross that made it reported it (select_and_cross): the same rows, so the pass over
+        # them is not made a second time (63 us of a 1.78 ms generation at 8192 x 100k)
+        if self._gebv_of_store is not None:
+            return self._gebv_of_store
         if self.storage == "bits":
             g = self.eng.empty((self.n_local, self.eng.n_traits), torch.float32)
             self.eng.gather_packed(self._store, None, self.n_local, None, None, g)
@@ -308,4 +313,5 @@ class ShardedPopulation:
             cap = largest
         self._cap_hint = self._next_cap(k, largest)
         self._store = out
+        self._gebv_of_store = gebv
         return DeviceArray.wrap(gebv)
