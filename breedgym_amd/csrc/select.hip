@@ -340,7 +340,11 @@ int topk_impl(bh_ctx *c, const float *d_scores, int64_t n_rows, int64_t n, int64
   while (cs < 8 * k && cs < kTopkChunk) cs <<= 1;
   if (n <= kTopkChunk) cs = kTopkChunk;  // a row one workgroup sorts whole
   const int64_t chunks0 = (n + cs - 1) / cs;
-  if (n > kTopkChunk && chunks0 * k > kTopkChunk) {
+  // ... and rows of 4097 .. 16384 scores with at most half of them wanted: one workgroup's bitonic sort of the whole row
+  // (padded to a power of two) costs P log^2 P whatever k is -- 68 us at 8192, 144 us at 16384 -- where four histogram
+  // passes and a sort of the k winners take 42 and 52-67 us (round 5; at 4096 and below the sort is as fast)
+  const bool select_mid = n > 4096 && n <= kTopkChunk && 2 * k <= n;
+  if (select_mid || (n > kTopkChunk && chunks0 * k > kTopkChunk)) {
     bh::TopkSelectParams q{};
     q.scores = d_scores;
     q.out_idx = d_idx_out;

@@ -135,3 +135,23 @@ def test_release_scratch_then_draw_again(layout):
     eng.release_scratch()
     ref_a, _ = co.selection_actions(s, 300, 2000, key0)
     assert np.array_equal(got.cpu().numpy(), ref_a)
+
+
+@pytest.mark.parametrize("n,k", [(4097, 1), (4097, 2048), (5000, 300), (8192, 25), (8192, 819), (8192, 4096), (12345, 1234),
+                                 (16384, 1638), (16384, 8192)])
+def test_topk_mid_rows_by_radix_select(n, k, rng):
+    """Rows of 4097 .. 16384 scores with at most half wanted go through the radix select + a sort of the winners (round 5;
+    before: one workgroup's sort of the whole row): jax.lax.top_k's order -- ties to the lower index, -0 below +0,
+    infinities -- on scores that are MOSTLY ties, several rows at once."""
+    import torch
+    from breedgym_amd import HipEngine
+
+    eng = HipEngine(np.full(64, 0.01, np.float32), np.ones((64, 1), np.float32))
+    s = np.round(rng.normal(0, 2, (3, n))).astype(np.float32)  # a handful of distinct values
+    s[0, rng.integers(0, n, 40)] = np.inf
+    s[1, rng.integers(0, n, 40)] = -np.inf
+    s[2, rng.integers(0, n, n // 3)] = -0.0
+    s[2, rng.integers(0, n, n // 3)] = 0.0
+    got = eng.topk(torch.from_numpy(s).to(eng.device), k).cpu().numpy()
+    for e in range(3):
+        assert np.array_equal(got[e], co.topk(s[e], k)), (n, k, e)
