@@ -221,6 +221,7 @@ KERNELS = {
     "c3_cross": ("packed_long_kernel<1, 8>", "c3"),
     "c3_finish": ("mask_finish4_kernel", "c3"),
     "c3_gebv": ("gebv_bits_kernel<1, 4>", "c3"),
+    "c3_reward": ("reward_max_kernel", "c3"),
     "c5_bytes": ("gebv_bytes_kernel<2>", "c5"),
     "c5_bits": ("gebv_bits_regs_kernel<2>", "c5"),
 }
@@ -437,35 +438,37 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
         actions = [torch.from_numpy(arng.integers(0, n, (E, n, 2), dtype=np.int32)).to(env.device) for _ in range(4)]
         env.reset(seed=7)
         dt, _ = time_steps(env, actions, steps, warmup, barrier)
-        # (both through eng.cross_packed on blocks of their own: the GEBV pass is the difference of the two)
-        kms_all = time_cross_launches(env, actions, max(10, steps), own_path=False)
-        kms = time_cross_launches(env, actions, max(10, steps), with_gebv=False, own_path=False)
+        # the launches a step issues, on the env's own blocks in its own alternation (StepRing.step, as the headline's):
+        # the long-row launch, the finish, the GEBV pass, the reward reduction -- without the resets
+        kms_step = time_cross_launches(env, actions, max(10, steps), with_reward=True)
         nbytes = cross_bytes(M, E * n, n, "bits", obs)
         site_bytes = 2 * 4 * n * (M // 128 + 2) * 8  # site words written by the launch and read back by the finish kernel
-        t_long, src_long = committed_traffic("c3_cross")
-        t_fin, _ = committed_traffic("c3_finish")
-        t_gebv, src_gebv = committed_traffic("c3_gebv")
+        gebv_bytes = E * n * packed_pitch(M) + M * 64   # the offspring's bit planes read again + the digit operands
+        seq = ("c3_cross", "c3_finish", "c3_gebv", "c3_reward")
+        traffic = [committed_traffic(w) for w in seq[:3]]
         eager = obs == "eager"  # (the PMC passes are of the eager configuration)
-        gebv_ms = kms_all - kms
+        cfg = "c3" if eager else "c3lazy"
+        us_gebv = profile_avg_us("c3_gebv", cfg)
         r = {"value": steps * E * n / dt, "unit": "crosses/s", "ms_per_step": dt / steps * 1e3,
              "roofline": roofline_of(
-                 "c3_cross", "long rows: four row waves stream rows without GEBV (LDS-DMA ring), eight mask waves draw the next "
-                 "generation's sites one gamete stream per lane -- 2048 keyed crosses x 100k markers of Threefry; then site "
-                 "words -> masks (the finish kernel)", nbytes + site_bytes, kms,
-                 binds="row role at 0.94 of the achievable ~6.3 TB/s when alone (415 us); beside it the mask role's integer issue "
-                       "(JAX's bit stream: 290 M VALU wave-instructions per launch) costs ~70 us of contention",
-                 extra_kernels=("c3_finish",), profile_cfg="c3" if eager else "c3lazy",
-                 traffic=(t_long + (t_fin or 0)) if eager and t_long else None, traffic_source=src_long if eager else None,
-                 api_level_GBps=6 * M * E * n / (kms * 1e-3) / 1e9),
-             "gebv_pass": roofline_of(
-                 "c3_gebv", "the GEBV of the step: a matrix-core pass over the bit-plane offspring the launch just wrote; whoever "
-                 "completes a cell writes its GEBV", E * n * packed_pitch(M) + M * 64, gebv_ms,
-                 binds="its rows (one column tile); ~10 us of ramp / first operands / way out around a stream at ~5 TB/s",
-                 profile_cfg="c3" if eager else "c3lazy",
-                 kernel_ms_is="difference of the timed launch sequence with and without the GEBV output (HIP events)",
-                 traffic=t_gebv if eager else None, traffic_source=src_gebv if eager else None),
-             "gebv_pass_ms": gebv_ms,
-             "step_frac_of_hbm_peak": (nbytes + E * n * packed_pitch(M)) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
+                 "c3_cross", "the launches of a step: the long-row launch -- four row waves stream rows without GEBV (LDS-DMA "
+                 "ring), eight mask waves draw the next generation's sites one gamete stream per lane: 2048 keyed crosses x 100k "
+                 "markers of Threefry --, site words -> masks (the finish kernel), the matrix-core GEBV pass over the offspring, "
+                 "the per-env reward reduction", nbytes + site_bytes + gebv_bytes, kms_step,
+                 binds="the long-row launch (0.48-0.53 of the ~0.58 ms): its row role runs at 0.94 of the achievable ~6.3 TB/s when "
+                       "alone (415 us) and the launch as a whole at 83 % of its integer issue (289.8 M VALU wave-instructions, most "
+                       "of them JAX's bit stream): two floors 0.1 ms apart; then ~0.1 ms of tail that is latency, not bytes",
+                 extra_kernels=seq[1:], profile_cfg=cfg,
+                 traffic=sum(t[0] for t in traffic) if eager and all(t[0] for t in traffic) else None,
+                 traffic_source=traffic[0][1] if eager else None,
+                 api_level_GBps=6 * M * E * n / (kms_step * 1e-3) / 1e9),
+             "gebv_pass": {"kernel": KERNELS["c3_gebv"][0], "bytes_per_launch": gebv_bytes, "profiles_avg_us": us_gebv[0],
+                           "frac_from_profiles": gebv_bytes / (us_gebv[0] * 1e-6) / 1e9 / HBM_PEAK_GBPS if us_gebv[0] else None,
+                           "profiles_source": us_gebv[2],
+                           "note": "the step's GEBV: a matrix-core pass over the bit-plane offspring the launch just wrote; timed by "
+                                   "rocprofv3 only (inside the step it cannot be told apart by events); its rows, ~10 us of ramp / "
+                                   "first operands / way out around a stream at ~5 TB/s"},
+             "step_frac_of_hbm_peak": (nbytes + site_bytes + gebv_bytes) / (dt / steps) / 1e9 / HBM_PEAK_GBPS}
         if name == "eager":
             out.update(r)
         else:

@@ -63,9 +63,9 @@ def test_committed_line_recomputes_from_the_committed_profiles():
                 us, _ = stats_avg_us(cfg or cfg0, name)
                 tot += us
         assert r["frac_from_profiles"] == pytest.approx(r["bytes_per_launch"] / (tot * 1e-6) / 1e9 / 8000.0, rel=2e-3), path
-        # ... and the two clocks agree: 3 % where a kernel is timed alone; the configs[2] figures come from another box
-        # than the profile's and, for the GEBV pass, from a difference of two launch sequences
-        tol = 0.03 if not path.startswith("configs.c3") else 0.12 if "gebv_pass" in path else 0.04
+        # ... and the two clocks agree: 3 % where a kernel is timed alone; configs[2]'s line and profile come from different
+        # boxes of the pool, which differ most on HBM-bound shapes
+        tol = 0.03 if not path.startswith("configs.c3") else 0.06  # (configs[2] moves most from box to box: HBM-bound)
         if "lazy" not in path:
             assert abs(r["frac"] - r["frac_from_profiles"]) <= tol * r["frac_from_profiles"], (path, r["frac"], r["frac_from_profiles"])
         if r.get("traffic") is not None:
