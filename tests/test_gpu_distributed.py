@@ -113,13 +113,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu(mode):
 
 
 @pytest.mark.timeout(900)
-def test_bench_self_launch_five_ranks_on_one_gpu():
-    """The widest rehearsal one GPU box allows: its process guard admits six processes on the card, and this test
-    process is one of them -- so five ranks, not the eight the driver runs on an 8-GPU node.  Env-sharded, the env window
-    over 5 x 16 envs; every rank must be seen."""
-    line = _one_line(_bench("--gpus", "5", "--oversubscribe", "--headline-only", "--steps", "5", "--warmup", "2", "--long-steps", "0"))
+def test_bench_self_launch_four_ranks_on_one_gpu():
+    """A wider rehearsal than two ranks, inside what one GPU box allows: its process guard admits six processes on the
+    card, this test process is one of them and whatever runs the suite may be another -- so four ranks, not the eight the
+    driver runs on an 8-GPU node (five have run too: profiles/r05_soak.txt).  Env-sharded, the env window over 4 x 16
+    envs; every rank must be seen."""
+    line = _one_line(_bench("--gpus", "4", "--oversubscribe", "--headline-only", "--steps", "5", "--warmup", "2", "--long-steps", "0"))
     d = line["distributed"]
-    assert line["n_gpus"] == 5 and d["ranks_seen"] == 5 == d["world_size"] and "oversubscribed" in d
+    assert line["n_gpus"] == 4 and d["ranks_seen"] == 4 == d["world_size"] and "oversubscribed" in d
     assert line["value"] > 0 and "value_long" not in line
 
 
