@@ -138,3 +138,38 @@ def test_bench_self_launch_exits_nonzero_when_a_rank_is_killed():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
     assert "rank exit codes" in r.stderr and "-9" in r.stderr, r.stderr[-1500:]
     assert time.monotonic() - t0 < 400
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["envs", "population"])
+def test_bench_under_torchrun_with_rccl_one_rank(mode):
+    """The driver's spelling for N > 1 -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`` -- with the one rank a one-GPU box allows: the process group comes
+    up over RCCL (backend "nccl", device_id given), the timing all-reduces and -- in population mode -- the all-gathers
+    of candidates and of the winners' rows go through RCCL.  One rank moves no bytes between GPUs; what this shows is
+    that the RCCL code path of both modes executes (rounds 1-4 never ran it)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_BACKEND")}
+    steps = ("--steps", "20", "--warmup", "5", "--long-steps", "100", "--headline-only") if mode == "envs" else ("--steps", "3", "--warmup", "1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", *steps, "--mode", mode],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    d = line["distributed"]
+    assert d["backend"] == "nccl (RCCL)" and d["ranks_seen"] == 1 == d["world_size"] and d["launcher"] == "torch.distributed.run"
+    assert "oversubscribed" not in d and line["n_gpus"] == 1 and line["value"] > 0
+    if mode == "population":
+        assert line["generations_redone"] == 0 and "8192 individuals" in line["config"]["workload"]
