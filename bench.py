@@ -26,9 +26,13 @@ sharded row-wise over the ranks; a step is one generation of ``ShardedPopulation
 (local GEBV -> local top-k -> RCCL all-gather of candidates -> global top-k -> RCCL all-gather of the
 winners' bit-plane rows -> every rank crosses its shard); weak scaling as well (8192 per rank).
 
-The JSON line also carries, at N = 1: ``roofline`` (dominant kernel of the headline: bytes it must
-move for the storage in use / its HIP-event time / 8 TB/s), ``configs`` (configs[2] and configs[4]
-timed the same way), ``cpu_baseline`` (the C oracle on the host's cores).
+The JSON line also carries, at N = 1: ``roofline`` (dominant kernel of the headline, named as rocprofv3 prints it
+(KERNELS): ``frac`` = bytes it must move for the storage in use / its HIP-event time as a step issues it / 8 TB/s;
+``frac_from_profiles`` = the same bytes / the committed rocprofv3 average of that kernel (profiles/<ROUND>_kernel_stats_*);
+``traffic`` = memory-side bytes per launch from PMC counters, measured by this run in child passes under
+``rocprofv3 --pmc`` with the kernel's FETCH_SIZE factor (FETCH_FACTORS); ``bound`` = the roofline priced against,
+``binds`` = what really limits the launch), ``configs`` (configs[2], configs[3] as one rank sees it and configs[4], the
+same way), ``cpu_baseline`` (the C oracle on the host's cores; the NumPy restatement and one C thread beside it).
 
 Prints ONE JSON line on rank 0.
 """
