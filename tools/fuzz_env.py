@@ -17,6 +17,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 
 from breedgym_amd import VecBreedGym, rng as hrng
+from breedgym_amd.vector import SelectionScores
 from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
 from oracle import c_oracle as co
 
@@ -46,6 +47,12 @@ def one_case(case):
               reward_shaping=shaping, env_rng=env_rng, storage=storage, observations=observations, genetic_map=gm)
     what = f"case {case}: E={E} n={n} N={N} M={M} T={T} G={G} {storage}/{observations} {env_rng} shaping={shaping} autoreset={autoreset}"
     env = VecBreedGym(**kw)
+    # a third of the cases step through SelectionScores (vec_wrappers.py:15-86): scores in, the k best paired at random,
+    # the env key advanced by its shuffle every step -- which voids everything drawn ahead, every step
+    wrap_k = int(rng.integers(2, min(n, 12) + 1)) if n >= 3 and rng.random() < 0.33 else 0
+    wrap_nc = int(rng.integers(1, min(wrap_k * (wrap_k - 1) // 2, n) + 1)) if wrap_k else 0
+    stepper = SelectionScores(env, k=wrap_k, n_crosses=wrap_nc) if wrap_k else env
+    what += f" SelectionScores(k={wrap_k}, n_crosses={wrap_nc})" if wrap_k else ""
     mode = 0 if env_rng == "shared" else 1
     seed = int(rng.integers(0, 2**31))
     pop, info = env.reset(seed=seed)
@@ -64,8 +71,13 @@ def one_case(case):
         if step_idx == G and not autoreset:
             roll = 0.95  # the episode is over and nothing resets it: reset by hand
         if roll < 0.72:
-            a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
-            pop, rews, ter, tru, info = env.step(a)
+            if wrap_k:
+                sc = np.round(rng.normal(0, 2, (E, n)), int(rng.integers(0, 3))).astype(np.float32)  # scores with ties
+                a, env_key = co.selection_actions(sc, wrap_k, wrap_nc, env_key)
+                pop, rews, ter, tru, info = stepper.step(sc)
+            else:
+                a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
+                pop, rews, ter, tru, info = env.step(a)
             ref, sim_key = co.cross(ref, a, gm.recombination_vec, sim_key, mode)
             step_idx += 1
             done = step_idx == G
@@ -92,7 +104,7 @@ def one_case(case):
             f, env_key = co.founders(co.key_from_seed(seed), E, N, n)
             ref, sim_key, step_idx = geno.view(np.uint8)[f], co.key_from_seed(seed), 0
             check_reset(pop, info, n, f"event {ev}: reset(seed)")
-        elif roll < 0.91:  # a population size of another kind (vec_env.py:118-119)
+        elif roll < 0.91 and not wrap_k:  # a population size of another kind (vec_env.py:118-119)
             n = int(rng.integers(1, min(N, 400) + 1))
             pop, info = env.reset(options={"individual_per_gen": n})
             f, env_key = co.founders(env_key, E, N, n)
@@ -107,6 +119,7 @@ def one_case(case):
             state = env.get_state()
             env = VecBreedGym(**{**kw, "individual_per_gen": n})
             env.set_state(state)
+            stepper = SelectionScores(env, k=wrap_k, n_crosses=wrap_nc) if wrap_k else env
             assert np.array_equal(u8(env.populations, ref.shape), ref), what + f": event {ev}: set_state"
         for obs, must in kept:
             assert np.array_equal(u8(obs, must.shape), must), what + f": event {ev}: an observation the caller kept was overwritten"
