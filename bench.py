@@ -930,9 +930,9 @@ def main():
                 binds="not HBM: the working set (two recycled 82 MB observation blocks + 10 MB of state) lives in the 256 MB "
                       "Infinity Cache and the launch is byte-insensitive (without the 82 MB observation: lazy_observations.kernel_ms). "
                       "What binds is the chip's store path -- a kernel of this grid that does nothing but these stores takes 14.0 us "
-                      "per back-to-back launch (6.6 TB/s) and 18.5 us with the ~5 us this launch needs before its first store "
-                      "(dispatch, indices, first words): profiles/r05_store_ceiling.txt -- and that fixed head; the mask role beside "
-                      "the row streams costs 1.8 us; the HBM fraction is kept as the stated convention",
+                      "per back-to-back launch (6.6 TB/s) and 16.6 us with the ~3 us this launch needs before its first store "
+                      "(entry barrier, indices, first words): profiles/r05_store_ceiling.txt -- and that fixed head; the mask role "
+                      "beside the row streams costs 1.8 us, the way out ~1.1; the HBM fraction is kept as the stated convention",
                 traffic=traffic, traffic_source=traffic_source, kernel_ms_without_reward=kern_ms_noreward,
                 bytes_model="per cross: 2 x M/4 parents read + M/4 state written + 2M observation written; per keyed "
                             "cross: M/4 mask row read + M/4 written for the next generation",
