@@ -73,7 +73,7 @@ bh::MaskParams mask_params(const bh_ctx *c, int buf, uint32_t key0, uint32_t key
   m.alwA = c->d_alwA;
   m.alwB = c->d_alwB;
   m.thr_bytes = (uint32_t)(c->nthr * 4);
-  m.zpitch = (int64_t)16 * c->nw;
+  m.zpitch = (int64_t)16 * c->zw;
   m.M = (int32_t)c->M;
   m.half = c->half;
   m.nwh = c->nwh;
@@ -435,7 +435,7 @@ int mutate_rows(bh_ctx *c, uint32_t key0, uint32_t key1, int64_t nkeys, KeyWindo
   ap.shared = shared;
   ap.dh = dh;
   ap.outp = d_out_packed;
-  ap.ppitch = 8 * (int64_t)c->nw;
+  ap.ppitch = 8 * (int64_t)c->pw;
   ap.outb = d_out_bytes;
   ap.bpitch = c->pitch;
   const int64_t threads = rows * ((c->M + 7) / 8);
@@ -455,7 +455,7 @@ bh::RowParams base_params(const bh_ctx *c) {
   p.scale = c->d_scale;
   p.pitch = c->pitch;
   p.effPitch = c->effPitch;
-  p.zpitch = (int64_t)16 * c->nw;
+  p.zpitch = (int64_t)16 * c->zw;
   p.nvec = c->nvec;
   p.T = (int32_t)c->T;
   return p;
@@ -468,9 +468,9 @@ bh::PackedParams packed_params(const bh_ctx *c) {
   p.scale = c->d_scale;
   p.pitch = c->pitch;
   p.effPitch = c->effPitch;
-  p.zpitch = (int64_t)16 * c->nw;
+  p.zpitch = (int64_t)16 * c->zw;
   p.nvec = c->nvec;
-  p.nvp = 8 * c->nw;
+  p.nvp = 8 * c->pw;
   p.T = (int32_t)c->T;
   p.spare = c->d_spare;
   p.err = c->d_err;
@@ -570,7 +570,7 @@ int run_gather(bh_ctx *c, const GatherPlan &g, const uint16_t *d_src, int64_t sr
     q.src = reinterpret_cast<const uint8_t *>(d_src);
     q.dst = reinterpret_cast<uint8_t *>(p.outp);
     q.idx = d_idx;
-    q.row_bytes = (int64_t)16 * c->nw;
+    q.row_bytes = (int64_t)16 * c->pw;
     q.n_pool = (int32_t)src_rows;
     q.n_rows = (int32_t)n_rows;
     hipLaunchKernelGGL(bh::packed_copy_rows_kernel, dim3((unsigned)((q.row_bytes / 16 + 1023) / 1024), (unsigned)n_rows), dim3(256), 0,
@@ -678,14 +678,14 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     if (pool_rows == 0) return fail(BH_ERR_BAD_ARG, "%s: empty parent pool", who);
     if (d_gebv && c->T == 0) return fail(BH_ERR_BAD_ARG, "%s: GEBV requested but the context has no traits", who);
     if (d_reward && !d_gebv) return fail(BH_ERR_BAD_ARG, "%s: the reward needs the GEBV output", who);
-    const int64_t row_bytes = packed ? (int64_t)16 * c->nw : c->pitch;
+    const int64_t row_bytes = packed ? (int64_t)16 * c->pw : c->pitch;
     const uint8_t *pool_lo = static_cast<const uint8_t *>(d_pool), *pool_end = pool_lo + n_envs * pool_rows * row_bytes;
     const uint8_t *out_lo = packed ? reinterpret_cast<const uint8_t *>(d_out_packed) : d_out_bytes;
     const uint8_t *out_end = out_lo + rows * row_bytes;
     if (out_lo < pool_end && pool_lo < out_end) return fail(BH_ERR_BAD_ARG, "%s: the output aliases the pool", who);
 
     // ---- this generation's masks: made by the previous call's launch, or made now
-    const int64_t zbytes = B * 16 * c->nw;
+    const int64_t zbytes = B * 16 * c->zw + 128;  // (+ a line: a row role asks for pw words of every mask row)
     int buf;
     if (c->pf.valid && c->pf.key0 == sim_key[0] && c->pf.key1 == sim_key[1] && c->pf.B == B && c->pf.dh == dh &&
         c->pf.off == kw.off && c->pf.total == kw.total) {
@@ -738,7 +738,7 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
     bh::MaskParams mp{};
     int mw = 1;
     if (run_ahead) {
-      if (int rc = ensure_z(c, 1 - buf, Bn * 16 * c->nw)) return rc;
+      if (int rc = ensure_z(c, 1 - buf, Bn * 16 * c->zw + 128)) return rc;
       mw = mask_waves_for_runahead(c, Bn, rows);
       mp = mask_params(c, 1 - buf, nk.x, nk.y, Bn, mw, dhn, kwn);
     }
@@ -935,7 +935,7 @@ int bh_step(bh_ctx *c, int64_t slot, int64_t reward_slot, int64_t prime_slot, co
                     prime_slot >= 0 ? static_cast<float *>(r.reward[(size_t)prime_slot]) : nullptr, r.reward_pitch);
 }
 
-int64_t bh_packed_pitch(const bh_ctx *c) { return c ? (int64_t)16 * c->nw : 0; }
+int64_t bh_packed_pitch(const bh_ctx *c) { return c ? (int64_t)16 * c->pw : 0; }
 
 int bh_pack(bh_ctx *c, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed) {
   if (int rc = check_ctx(c)) return rc;
@@ -948,7 +948,7 @@ int bh_pack(bh_ctx *c, const uint8_t *d_rows, int64_t n_rows, uint16_t *d_packed
   p.dst = d_packed;
   p.pitch = c->pitch;
   p.nvec = c->nvec;
-  p.nvp = 8 * c->nw;
+  p.nvp = 8 * c->pw;
   p.n_rows = (int32_t)n_rows;
   return launch_pack(c, p);
 }

@@ -47,6 +47,11 @@ struct bh_ctx {
   hipStream_t stream = nullptr;
   int64_t M = 0, T = 0, pitch = 0;
   int32_t half = 0, nwh = 0, nw = 0, nvec = 0;
+  // 16-byte words from one bit-plane row (and one row of crossover masks) to the next: nw, and whole 128-byte lines for
+  // rows beyond 4 KB (bh_create) -- what bh_packed_pitch() hands out.  Words nw .. pw - 1 are padding like the bits past
+  // marker M: zero in every row the library writes, never looked at as markers.
+  int32_t pw = 0;
+  int32_t zw = 0;  // ... and from one row of crossover masks to the next
   int64_t effPitch = 0;
   uint32_t *d_thrA = nullptr, *d_thrB = nullptr;  // 32-bit thresholds (thr23 << 9)
   uint32_t *d_ctrB = nullptr;                     // second Threefry counter per pair

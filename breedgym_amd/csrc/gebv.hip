@@ -143,7 +143,7 @@ int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d
     p.idx = d_idx;
     p.B = static_cast<const bh::i32x4 *>(c->d_Bbits[g]);
     if (int rc = gebv_out(c, rows, row_groups, group_rows, slices, t0, tn, d_gebv, &p.out)) return rc;
-    p.row_bytes = (int64_t)16 * c->nw;
+    p.row_bytes = (int64_t)16 * c->pw;
     p.n_src = (int32_t)n_src;
     p.n_rows = (int32_t)rows;
     p.n_mc = c->n_mc;

@@ -176,7 +176,7 @@ struct GebvBitsParams {
   const int32_t *idx;   // (n_rows) source row of output row i, or null (= i)
   const i32x4 *B;       // [mc][q 4][ntile 2][j 4][lane 64] 16 int8 each
   GebvOut out;
-  int64_t row_bytes;    // 16 * ceil(M / 64)
+  int64_t row_bytes;    // bh_packed_pitch(): 16 * ceil(M / 64), whole 128-byte lines beyond 4 KB
   int32_t n_src, n_rows;
   int32_t n_mc;          // ceil(M / 512)
   int32_t row_groups, slices;  // the grid: 8 * row_groups * ceil(slices / 8) workgroups (slice_of_block)
@@ -246,7 +246,11 @@ __device__ __forceinline__ void static_for(Fn f) {
 // macro-chunk, and a row's start again) and the LDS reads of DMA-written data are inline asm, so that the compiler,
 // which would wait for the NEWEST DMA before any LDS read, stays out of it (packed_dma.h has the same arrangement).
 // Digits beyond marker M are zero in the pack, so bytes beyond a row's end may be anything: only their address is
-// kept inside the row.
+// kept inside the row.  (Rows of more than 4 KB start on 128-byte lines -- bh_packed_pitch -- so a macro-chunk of a row
+// IS a line.  At the old pitch, 25,008 bytes for 100,000 markers, every piece of 128 bytes straddled two and the pass
+// over 8192 rows took 52 us instead of 40 with its rows in the Infinity Cache: profiles/r05_ab_pitch.txt.  Measured
+// there as well, and no help inside the step: two macro-chunks of rows in flight instead of one, and pulling the
+// rows' lines into the L2 ahead of the DMAs with a 4-byte LDS-DMA per row.)
 constexpr int kBitsF = 2;               // 32-row tiles per wave
 constexpr int bits_rows(int waves) { return waves * kBitsF * 32; }  // rows per workgroup = rows per row group
 constexpr int kBitsRing = 3;            // superstages of digit operands in LDS

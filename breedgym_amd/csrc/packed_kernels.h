@@ -54,9 +54,9 @@ struct PackedParams {
   const double *scale;  // (T) 2^-s_t of the fixed-point effects
   int64_t pitch;        // bytes per byte-layout row
   int64_t effPitch;
-  int64_t zpitch;       // bytes per mask row = bytes per packed row = 16 * nw
+  int64_t zpitch;       // bytes per mask row = bytes per packed row = 16 * pw (ctx.h)
   int32_t nvec;         // 16-byte vectors per byte-layout row = ceil(M / 8)
-  int32_t nvp;          // uint16 words per packed row = 8 * nw >= nvec
+  int32_t nvp;          // uint16 words per packed row = 8 * pw: nvec <= nvp < nvec + 64, words nvec .. nvp - 1 zero
   int32_t n_pool, n_out;
   int32_t n_rows;
   int32_t n_blocks;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void packed_stream_role(const PackedParams &p, const 
         trip(base + 128 * VPT, wc, wb);
       }
     }
-    if (p.nvec + lane < p.nvp) {  // padding words: markers beyond M, up to the next multiple of 64
+    if (p.nvec + lane < p.nvp) {  // padding words: markers beyond M, up to the pitch (fewer than 64: ctx.h, pw)
 #pragma unroll
       for (int r = 0; r < R; ++r) dstp[r][p.nvec + lane] = 0;
     }
@@ -713,7 +713,7 @@ struct CopyRowsParams {
   const uint8_t *src;  // (n_pool, row_bytes) packed rows
   uint8_t *dst;        // (n_rows, row_bytes)
   const int32_t *idx;  // (n_rows) source row of every output row (JAX retrieval indexing), or null (= identity)
-  int64_t row_bytes;   // 16 * nw
+  int64_t row_bytes;   // 16 * pw
   int32_t n_pool, n_rows;
 };
 __global__ __launch_bounds__(256) void packed_copy_rows_kernel(const CopyRowsParams p) {

@@ -43,7 +43,7 @@ struct MaskParams {
   const uint32_t *ctrB;  // [(nwh+16)*64] second Threefry counter of pair j: j + half, or 0 where that is >= M
   const uint64_t *alwA;  // [nwh] site words that are always set (r >= 1), or null if there are none
   const uint64_t *alwB;
-  int64_t zpitch;        // bytes per cross = 16 * nw
+  int64_t zpitch;        // bytes per cross = 16 * pw (ctx.h): words nw .. pw - 1 are never written
   int32_t M, half, nwh, nw;
   int32_t n_rows;     // B: crosses with their own keys
   int32_t n_blocks;   // workgroups with mask waves = ceil(n_rows / (4 / WAVES))

@@ -305,7 +305,8 @@ class EngineBase:
         return torch.empty_strided((int(n_envs),), (64,), dtype=torch.float32, device=self.device)
 
     def empty_packed(self, rows: int) -> torch.Tensor:
-        """Bit-plane rows: ``packed_pitch = 16 * ceil(M / 64)`` bytes each (include/breedhip.h)."""
+        """Bit-plane rows: ``packed_pitch`` bytes each -- 16 per 64 markers, whole 128-byte lines beyond 4 KB
+        (``bh_packed_pitch``, include/breedhip.h)."""
         return torch.empty((int(rows), self.packed_pitch), dtype=torch.uint8, device=self.device)
 
     def as_genotypes(self, rows_t: torch.Tensor, *lead) -> DeviceArray:

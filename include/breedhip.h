@@ -246,7 +246,10 @@ int bh_winner_layout(bh_ctx *ctx, const int32_t *d_winners, int64_t k, int64_t n
  * (vec_env.py:57-62) -- but a population a VecBreedGym keeps between steps can live packed, 1 bit
  * per allele: a packed row is uint16 P[bh_packed_pitch() / 2]; bit i of P[v] is byte i of the 16-byte
  * vector v of the byte-layout row (markers 8v .. 8v+7: even bits allele 0, odd bits allele 1; i.e.
- * numpy packbits(row_bytes, bitorder="little")), zero beyond M.
+ * numpy packbits(row_bytes, bitorder="little")), zero beyond M.  bh_packed_pitch() = 16 bytes per 64 markers, rounded
+ * up to whole 128-byte lines when that is more than 4 KB (M > 16384: long rows start on cache lines -- a 100,000-marker
+ * row is 25,088 bytes apart from the next, not 25,008); the padding is zero in every row the library writes.  Ask for
+ * the pitch, do not compute it.
  * A step then reads M/2 bytes of parents per cross instead of 4M, and still hands out the same
  * byte-layout offspring when asked to. */
 int64_t bh_packed_pitch(const bh_ctx *ctx);

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 from golden_util import CASES, load_case
+from oracle_engine import packed_pitch_of
 
 from oracle import c_oracle as co
 
@@ -25,11 +26,10 @@ def gebv_close(got, ref64):
 
 
 def pack_numpy(g):
-    """(rows, M, 2) 0/1 -> (rows, 8 * nw) uint16 in the documented layout (include/breedhip.h): bit i of
+    """(rows, M, 2) 0/1 -> (rows, packed pitch / 2) uint16 in the documented layout (include/breedhip.h): bit i of
     word v = byte i of the 16-byte vector v of the byte-layout row."""
     rows, M, _ = g.shape
-    nw = (M + 63) // 64
-    by = np.zeros((rows, nw * 64 * 2), np.uint8)
+    by = np.zeros((rows, packed_pitch_of(M) * 8), np.uint8)
     by[:, : 2 * M] = g.reshape(rows, 2 * M)
     return np.packbits(by, axis=1, bitorder="little").view(np.uint16)
 
@@ -45,7 +45,7 @@ def test_pack_unpack_roundtrip(M, rng):
     eng = make_engine(np.full(M, 0.01, np.float32), np.ones((M, 1), np.float32))
     rows = eng.upload_population(g)
     pk = eng.pack(rows)
-    assert pk.shape == (N, eng.packed_pitch) and eng.packed_pitch == 16 * ((M + 63) // 64)
+    assert pk.shape == (N, eng.packed_pitch) and eng.packed_pitch == packed_pitch_of(M)
     assert np.array_equal(packed_host(pk), pack_numpy(g))
     back = eng.unpack(pk)
     assert np.array_equal(eng.download_population(back).view(np.uint8), g)

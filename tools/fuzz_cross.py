@@ -25,6 +25,7 @@ co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
 def pack_numpy(g):
     rows, M, _ = g.shape
     nw = (M + 63) // 64
+    nw = nw if nw <= 256 else (nw + 7) // 8 * 8  # bh_packed_pitch: whole 128-byte lines for rows beyond 4 KB
     by = np.zeros((rows, nw * 64 * 2), np.uint8)
     by[:, : 2 * M] = g.reshape(rows, 2 * M)
     return np.packbits(by, axis=1, bitorder="little").view(np.uint16)
