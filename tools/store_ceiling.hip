@@ -16,7 +16,10 @@
 constexpr int kRows = 4096, kNvec = 1250, kNvp = 1256;  // 16 x 256 offspring, 10k markers: 1250 16-byte vectors, 157 x 8 words
 constexpr int64_t kPitch = 20000, kPPitch = 2512;
 
-template <int POLICY>  // 0 plain, 16 sc1 (write-through), 2 nt
+// ALIGNED: the lanes of an instruction shifted along the row so that every instruction's KB (observation) and 128 bytes
+// (bit planes) start on a 128-byte line -- rows are 20,000 and 2,512 bytes apart, so as the stream has it (lane l: vector
+// 64 u + l) an observation store touches nine lines and a bit-plane store two.
+template <int POLICY, bool ALIGNED = false>  // 0 plain, 16 sc1 (write-through), 2 nt
 __global__ __launch_bounds__(512) void stores(uint8_t *obs, uint16_t *state, int spin) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave >= 4) return;  // the mask waves' place
@@ -31,12 +34,15 @@ __global__ __launch_bounds__(512) void stores(uint8_t *obs, uint16_t *state, int
     const int row = ((int)blockIdx.x * 4 + wave) * 2 + r;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (int64_t)row * kPitch), 0, (int)kPitch, 0x00020000);
     uint16_t *sp = state + (int64_t)row * kNvp;
-    for (int base = 0; base < kNvec; base += 128) {  // two vectors per lane and trip, like the stream
+    const int so = ALIGNED ? (int)(((int64_t)row * kPitch & 127) >> 4) : 0;   // vectors from the line's start to the row's
+    const int ss = ALIGNED ? (int)(((int64_t)row * kPPitch & 127) >> 1) : 0;  // words
+    for (int base = 0; base < kNvec + (so > ss ? so : ss); base += 128) {  // two vectors per lane and trip, like the stream
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        int i = base + 64 * u + lane;
-        i = i < kNvec ? i : kNvec - 1;
-        sp[i] = (uint16_t)i;
+        int i = base + 64 * u + lane - so, j = base + 64 * u + lane - ss;
+        i = i < 0 ? 0 : i < kNvec ? i : kNvec - 1;
+        j = j < 0 ? 0 : j < kNvec ? j : kNvec - 1;
+        sp[j] = (uint16_t)j;
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, 16 * i, 0, POLICY);
       }
     }
@@ -59,6 +65,7 @@ int main() {
     auto launch = [&](int i) {
       if (policy == 0) hipLaunchKernelGGL(stores<0>, dim3(512), dim3(512), 0, 0, obs[i & 1], state[i & 1], spin);
       else if (policy == 16) hipLaunchKernelGGL(stores<16>, dim3(512), dim3(512), 0, 0, obs[i & 1], state[i & 1], spin);
+      else if (policy == 17) hipLaunchKernelGGL((stores<16, true>), dim3(512), dim3(512), 0, 0, obs[i & 1], state[i & 1], spin);
       else hipLaunchKernelGGL(stores<2>, dim3(512), dim3(512), 0, 0, obs[i & 1], state[i & 1], spin);
     };
     for (int i = 0; i < 200; ++i) launch(i);  // clocks settle
@@ -79,6 +86,7 @@ int main() {
   for (double d : {0.0, 3.0, 5.0}) {
     run("plain stores", 0, d);
     run("write-through (sc1: the stream's)", 16, d);
+    run("write-through, instructions on lines", 17, d);
     run("non-temporal (nt)", 2, d);
   }
   return 0;
