@@ -8,7 +8,7 @@ from .engine import DeviceArray, HipEngine, PackedPopulation
 from .simulator import Simulator, TraitModel
 from .vector.vec_env import VecBreedGym
 
-__version__ = "0.5.0"  # = the library's (bh_version(); tests/test_abi.py compares them)
+__version__ = "0.5.1"  # = the library's (bh_version(); tests/test_abi.py compares them)
 __all__ = ["BreedGym", "VecBreedGym", "Simulator", "TraitModel", "HipEngine", "DeviceArray", "PackedPopulation",
            "REGISTRY", "make"]
 

@@ -49,7 +49,7 @@ using namespace bhh;
 
 extern "C" {
 
-const char *bh_version(void) { return "breedhip 0.5.0 (gfx950)"; }
+const char *bh_version(void) { return "breedhip 0.5.1 (gfx950)"; }
 const char *bh_last_error(void) { return bhh::g_err; }
 
 int bh_device_count(int *count) {

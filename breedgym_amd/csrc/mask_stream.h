@@ -246,16 +246,22 @@ __global__ __launch_bounds__(256) void mask_sites_kernel(const MaskParams p) {
 // site_word (row_kernels.h) for the planar site array of one cross: the 64 site bits of markers [64w, 64w + 64) of
 // gamete g; plane 2g holds the A words (markers [0, half) from bit 0 of word 0), plane 2g + 1 the B words
 // (markers [half, M)); the word behind the last one of a plane is zero.
+// Without a branch, for any w in [0, nw): a word of the A plane (or its zero word), and 16 bytes of the B plane's string
+// from the word the bit 64 w - half lies in -- the word in FRONT of plane B is plane A's zero word, the word behind its
+// last its own.  (Round 5: as three cases under lane conditions -- whole word in A, whole word in B at a bit offset
+// from two loads, the one word that straddles -- the finish kernels came out as 190 branches with a wait for the loads
+// behind each: "all loads in flight together" was not what ran.  2048 x 100k: 37 -> 29 us, profiles/r05_ab_finish.txt.)
 __device__ __forceinline__ uint64_t site_word_planar(const uint64_t *S, int spitch, int g, int w, int half) {
   const uint64_t *SA = S + (int64_t)(2 * g) * spitch, *SB = SA + spitch;
-  const int base = w << 6;
-  if (base + 64 <= half) return SA[w];
-  if (base >= half) {
-    const int off = base - half, k = off >> 6, sh = off & 63;
-    const uint64_t lo = SB[k];
-    return sh ? ((lo >> sh) | (SB[k + 1] << (64 - sh))) : lo;
-  }
-  return SA[w] | (SB[0] << (half - base));
+  const int nwh = spitch - 1;
+  const uint64_t a = SA[w < nwh ? w : nwh];
+  const int off = (w << 6) - half;  // the word's first bit in plane B's string (negative: in front of it)
+  const int k = (off >> 6) > -1 ? (off >> 6) : -1, sh = off & 63;
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+  const u64x2 b = *reinterpret_cast<const u64x2 *>(SB + k);
+  const uint64_t lo = b.x >> sh;
+  const uint64_t hi = (sh != 0 && off >= -64) ? b.y << (64 - sh) : 0ull;
+  return a | lo | hi;
 }
 
 // Phase B of mask_role over site words in memory: one wave per cross, inclusive prefix-XOR of the site strings,
@@ -275,8 +281,10 @@ __global__ __launch_bounds__(256) void mask_finish_kernel(const MaskParams p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int w = w0 + 64 * u + lane;
-      s0[u] = w < p.nw ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
-      s1[u] = w < p.nw ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
+      const int wc = w < p.nw ? w : p.nw - 1;  // (every lane loads: a load under a lane condition is a branch)
+      const uint64_t v0 = site_word_planar(S, p.spitch, 0, wc, p.half), v1 = site_word_planar(S, p.spitch, 1, wc, p.half);
+      s0[u] = w < p.nw ? v0 : 0ull;
+      s1[u] = w < p.nw ? v1 : 0ull;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -323,8 +331,10 @@ __global__ __launch_bounds__(256) void mask_finish4_kernel(const MaskParams p) {
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
         const int w = w_lo + 64 * u + lane;
-        k0[u] = w < w_hi ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
-        k1[u] = w < w_hi ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
+        const int wc = w < p.nw ? w : p.nw - 1;  // (every lane loads: a load under a lane condition is a branch)
+        const uint64_t v0 = site_word_planar(S, p.spitch, 0, wc, p.half), v1 = site_word_planar(S, p.spitch, 1, wc, p.half);
+        k0[u] = w < w_hi ? v0 : 0ull;
+        k1[u] = w < w_hi ? v1 : 0ull;
       }
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
@@ -377,8 +387,10 @@ __global__ __launch_bounds__(256) void mask_finish4_kernel(const MaskParams p) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int w = w0 + 64 * u + lane;
-        s0[u] = w < w_hi ? site_word_planar(S, p.spitch, 0, w, p.half) : 0ull;
-        s1[u] = w < w_hi ? site_word_planar(S, p.spitch, 1, w, p.half) : 0ull;
+        const int wc = w < p.nw ? w : p.nw - 1;
+        const uint64_t v0 = site_word_planar(S, p.spitch, 0, wc, p.half), v1 = site_word_planar(S, p.spitch, 1, wc, p.half);
+        s0[u] = w < w_hi ? v0 : 0ull;
+        s1[u] = w < w_hi ? v1 : 0ull;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) block(w0 + 64 * u + lane, s0[u], s1[u]);
