@@ -296,6 +296,7 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_dig16) (void)hipFree(c->d_dig16);
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->d_gsum) (void)hipFree(c->d_gsum);
+  if (c->d_pool_gebv) (void)hipFree(c->d_pool_gebv);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
   if (c->d_effsum) (void)hipFree(c->d_effsum);
@@ -386,6 +387,7 @@ int bh_release_scratch(bh_ctx *c) {
   drop(c->d_sort, c->sort_cap);
   drop(c->d_best, c->best_cap);
   drop(c->d_gsum, c->gsum_cap);  // (zero whenever no launch is in flight: nothing is lost)
+  drop(c->d_pool_gebv, c->pool_gebv_cap);
   {
     void *p = c->d_partial;
     drop(p, c->partial_cap);

@@ -100,6 +100,8 @@ struct bh_ctx {
   int64_t partial_cap = 0;       // int32 words
   void *d_gsum = nullptr;  // gebv_bits.h, GebvOut: the final cells, then one set of cells per slice group
   int64_t gsum_cap = 0;    // bytes
+  void *d_pool_gebv = nullptr;  // gebv_bits: the GEBV of a pool's rows, on its way through an index (gebv.hip)
+  int64_t pool_gebv_cap = 0;
   // top-k scratch
   float *d_cand_s[2] = {nullptr, nullptr};
   int32_t *d_cand_i[2] = {nullptr, nullptr};

@@ -118,8 +118,36 @@ constexpr int kGebvBitsWaves = 4;  // two workgroups of four waves per CU (each 
 // more -- a second round of a few workgroups costs a whole round's time (784 workgroups: 117 us, 640: 91 us at
 // 2048 x 100k x 8, profiles/r03_ab_gebv_bytes.txt)
 constexpr int kGebvBytesWgs = 768;  // workgroups the K slicing aims at
+// (rows, T) values of a pool's rows through an index (JAX retrieval indexing, as the row kernels read it)
+__global__ __launch_bounds__(256) void gebv_through_index_kernel(const float *pool, const int32_t *idx, int n_src, int64_t n, int T,
+                                                                 float *out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = i / T;
+  const int t = (int)(i - row * T);
+  int s = idx[row];  // (row_kernels.h, norm_index: negative indices count from the end, what is still outside is clamped)
+  if (s < 0) s += n_src;
+  s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);
+  out[i] = pool[(int64_t)s * T + t];
+}
+
 int gebv_bits(bh_ctx *c, const uint16_t *d_rows, int64_t n_src, const int32_t *d_idx, int64_t rows, float *d_gebv) {
   constexpr int kTraitsPerPack = bh::kGebvCols / bh::kGebvDigits;
+  if (d_idx && rows >= 2 * n_src && n_src >= 32) {
+    // Many rows picked out of few (a reset's founders: 4 x 2048 out of a 2048-row germplasm at configs[2]): the pass over
+    // the POOL's rows -- a quarter of the bytes there -- and the values through the index; a row's GEBV is a function
+    // of its bits alone, so nothing changes but the time (67 -> 26 us per reset at configs[2]).
+    const int64_t need = n_src * c->T * (int64_t)sizeof(float);
+    if (int rc = ensure_scratch(c, &c->d_pool_gebv, &c->pool_gebv_cap, need)) return rc;
+    float *pool = static_cast<float *>(c->d_pool_gebv);
+    if (int rc = gebv_bits(c, d_rows, n_src, nullptr, n_src, pool)) return rc;
+    const int64_t n = rows * c->T;
+    hipLaunchKernelGGL(gebv_through_index_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pool, d_idx, (int)n_src, n,
+                       (int)c->T, d_gebv);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "gebv_through_index launch: %s", hipGetErrorString(e));
+    return BH_OK;
+  }
   for (size_t g = 0; g < c->d_Bbits.size(); ++g) {
     const int64_t t0 = (int64_t)g * kTraitsPerPack, tn = std::min<int64_t>(kTraitsPerPack, c->T - t0);
     const int nt = tn * bh::kGebvDigits > 32 ? 2 : 1;

@@ -155,6 +155,33 @@ def test_packed_traits(T, want_bytes, rng):
     assert gebv_close(g2.cpu().numpy(), co.gebv(pop[0], eff, want64=True)[1])
 
 
+@pytest.mark.parametrize("M,T,want_rows", [(20000, 1, False), (20000, 1, True), (1000, 3, False), (40000, 8, True)])
+def test_gebv_of_many_rows_out_of_few(M, T, want_rows, rng):
+    """A gather of many rows out of a small pool with the GEBV on the matrix cores (a reset's founders at configs[2]:
+    4 x 2048 out of 2048): the pass runs over the POOL and the values go through the index (gebv.hip, gebv_bits) --
+    indices that wrap and clamp included; with and without the rows themselves."""
+    N, R = 40, 173
+    pop = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eng = make_engine(np.full(M, 0.01, np.float32), eff)
+    ppool = eng.pack(eng.upload_population(pop))
+    gi = torch.from_numpy(rng.integers(-N - 1, N + 2, R, dtype=np.int32)).to(eng.device)
+    ii = gi.cpu().numpy().astype(np.int64)
+    ii = np.clip(np.where(ii < 0, ii + N, ii), 0, N - 1)
+    outp = eng.empty_packed(R) if want_rows else None
+    gg = eng.empty((R, T), torch.float32)
+    eng.gather_packed(ppool, gi, R, outp, None, gg)
+    assert gebv_close(gg.cpu().numpy(), co.gebv(pop[ii], eff, want64=True)[1])
+    if want_rows:
+        assert np.array_equal(packed_host(outp), pack_numpy(pop[ii]))
+    # ... and the same values as the pass over the gathered rows themselves gives, to the bit (three traits and more:
+    # both are the matrix-core pass)
+    if want_rows and T >= 3:
+        g2 = eng.empty((R, T), torch.float32)
+        eng.gather_packed(outp, None, R, None, None, g2)
+        assert torch.equal(g2, gg)
+
+
 def test_packed_equals_byte_path_over_generations(rng):
     """Ten generations, both layouts side by side from the same seed: same offspring, same keys, with
     the run-ahead masks of one layout's launches feeding the next call of the same layout."""
