@@ -724,9 +724,10 @@ __global__ __launch_bounds__(256) void packed_copy_rows_kernel(const CopyRowsPar
   const int i0 = p.idx ? norm_index(p.idx[row], p.n_pool) : row;
   const uint4 *s = reinterpret_cast<const uint4 *>(p.src + (int64_t)i0 * p.row_bytes);
   uint4 *d = reinterpret_cast<uint4 *>(p.dst + (int64_t)row * p.row_bytes);
-  uint4 t[4];
+  uint4 t[4];  // (every lane loads, one past the end its row's last piece: a load under a lane condition is a branch with a
+               // wait for the load behind it -- four trips to memory in a row instead of four loads in flight)
 #pragma unroll
-  for (int u = 0; u < 4; ++u) t[u] = piece0 + 64 * u < n_pieces ? s[piece0 + 64 * u] : make_uint4(0, 0, 0, 0);
+  for (int u = 0; u < 4; ++u) t[u] = s[piece0 + 64 * u < n_pieces ? piece0 + 64 * u : n_pieces - 1];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
     if (piece0 + 64 * u < n_pieces) d[piece0 + 64 * u] = t[u];
@@ -753,7 +754,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int v = v0 + 64 * u;
-    w[u] = v < p.nvec ? *reinterpret_cast<const uint4 *>(s + 16 * (int64_t)v) : make_uint4(0, 0, 0, 0);
+    // every lane loads, one past the end its row's last vector: under a lane condition -- also as "load, then select":
+    // the compiler turns a select on a loaded value back into a branch -- the eight loads were eight trips to memory
+    // in a row.  What a lane past the end packs is dropped below.
+    w[u] = *reinterpret_cast<const uint4 *>(s + 16 * (int64_t)(v < p.nvec ? v : p.nvec - 1));
   }
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)  // bit 0 of bytes 0..3 -> bits 4k .. 4k+3
       o |= (((dw[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);
-    if (v < p.nvp) d[v] = (uint16_t)o;  // zero words from the last marker up to the pitch
+    if (v < p.nvp) d[v] = (uint16_t)(v < p.nvec ? o : 0u);  // zero words from the last marker up to the pitch
   }
 }
 
