@@ -375,14 +375,19 @@ def live_traffic(timeout=90):
 def fetch_factor(kernel_name):
     """What FETCH_SIZE has to be multiplied by.  The guide's gfx950 correction (x 2) is for wide coalesced streaming
     reads (16 bytes per lane, consecutive lanes consecutive addresses), which the counter tallies at half their bytes.
-    Calibrated per kernel with variants that leave one kind of read out (rows only / operands only), one box each:
-      gebv_bits_kernel<1, 4>   rows and operands by LDS-DMA, eight lanes taking the eight 16-byte pieces of a 128-byte
-                               line in a permuted order: tallied IN FULL -- rows only 59.6 MB raw for 51.2 MB, operands only
-                               3.9 MB raw for 6.4 MB (profiles/r04_ab_gebv.txt, section 5)                          -> 1
-      gebv_bits_regs_kernel<2> rows by global_load_dwordx4, eight lanes per 128-byte line of each of eight rows per
-                               instruction, operands by global_load_dwordx4 of consecutive lanes: rows only 29.9 MB raw for
-                               51.2 MB (x 1.71), operands only 3.33 MB raw for 6.4 MB (x 1.92); blended by their raw shares
-                               0.90 / 0.10 (profiles/r05_pmc_calibration.txt)                                      -> 1.73
+    Calibrated per kernel where its reads are of another shape (profiles/r05_pmc_calibration.txt):
+      gebv_bits_regs_kernel<2> operands by global_load_dwordx4 of consecutive lanes: x 1.92 measured with the row reads
+                               left out (3.33 MB raw for 6.4 MB); rows by global_load_dwordx4, eight lanes per 128-byte
+                               line of each of eight rows per instruction.  While a 100k-marker row was 25,008 bytes and
+                               every such piece straddled two lines the rows were tallied at 58 % (x 1.71, blend 1.73);
+                               since long rows start on lines (bh_packed_pitch, second session of round 5) the raw count of
+                               the shipped kernel is 30.06 MB for 51.4 MB of rows + 6.4 MB of operands that cannot come
+                               from an L2: at least x 1.92 for both kinds -- whole aligned lines are tallied at half, as the
+                               guide says                                                                          -> 1.92
+      gebv_bits_kernel<1, 4>   rows and operands by LDS-DMA, eight lanes taking the eight 16-byte pieces of a line in a
+                               permuted order.  Straddling two lines each (round 4) they were tallied in full (59.6 MB raw
+                               for 51.2 MB); on lines the step's pass reads 113.7 MB raw for 205.5 MB of rows no cache can
+                               hold + 3.2 MB of operands: at least x 1.84                              -> the guide's x 2
     Every other kernel of the line reads 16 bytes per lane from consecutive addresses (or 2-byte words of consecutive
     lanes, small next to its stores): the guide's x 2."""
     n = norm_kernel(kernel_name)
@@ -392,7 +397,7 @@ def fetch_factor(kernel_name):
     return 2.0
 
 
-FETCH_FACTORS = {"gebv_bits_kernel<": 1.0, "gebv_bits_regs_kernel<": 1.73}
+FETCH_FACTORS = {"gebv_bits_regs_kernel<": 1.92}
 
 
 def committed_traffic(which):
@@ -459,9 +464,10 @@ def bench_c3(steps, warmup, barrier, variants=("eager", "lazy_observations")):
                  "ring), eight mask waves draw the next generation's sites one gamete stream per lane: 2048 keyed crosses x 100k "
                  "markers of Threefry --, site words -> masks (the finish kernel), the matrix-core GEBV pass over the offspring, "
                  "the per-env reward reduction", nbytes + site_bytes + gebv_bytes, kms_step,
-                 binds="the long-row launch (0.48-0.53 of the ~0.58 ms): its row role runs at 0.94 of the achievable ~6.3 TB/s when "
+                 binds="the long-row launch (0.47-0.50 of the ~0.56 ms): its row role runs at 0.94 of the achievable ~6.3 TB/s when "
                        "alone (415 us) and the launch as a whole at 83 % of its integer issue (289.8 M VALU wave-instructions, most "
-                       "of them JAX's bit stream): two floors 0.1 ms apart; then ~0.1 ms of tail that is latency, not bytes",
+                       "of them JAX's bit stream): two floors 0.1 ms apart; then ~0.09 ms of tail (finish 0.029, GEBV pass 0.055, reward 0.005) "
+                       "that runs behind the launch's 1.8 GB of stores",
                  extra_kernels=seq[1:], profile_cfg=cfg,
                  traffic=sum(t[0] for t in traffic) if eager and all(t[0] for t in traffic) else None,
                  traffic_source=traffic[0][1] if eager else None,

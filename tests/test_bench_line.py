@@ -90,7 +90,7 @@ def test_committed_traffic_never_answers_for_another_kernel(monkeypatch):
     assert b is None and "no committed" in src
     monkeypatch.setattr(bench, "_LIVE_TRAFFIC", {bench.norm_kernel("gebv_bits_regs_kernel<2>"): (6.0e7, 10, 33000.0, 5000.0)})
     b, src = bench.committed_traffic("c5_bits")
-    assert b == 6.0e7 and src.startswith("measured by this run") and "1.73 x FETCH_SIZE" in src
+    assert b == 6.0e7 and src.startswith("measured by this run") and "1.92 x FETCH_SIZE" in src
     assert bench.committed_traffic("ghost")[0] is None  # a prefix of a live name is not a match
-    assert bench.fetch_factor("void bh::gebv_bits_kernel<1, 4>(bh::GebvBitsParams)") == 1.0
-    assert bench.fetch_factor("bh::gebv_bytes_kernel<2>") == 2.0 and bench.fetch_factor("gebv_bits_regs_kernel<2>") == 1.73
+    assert bench.fetch_factor("void bh::gebv_bits_kernel<1, 4>(bh::GebvBitsParams)") == 2.0
+    assert bench.fetch_factor("bh::gebv_bytes_kernel<2>") == 2.0 and bench.fetch_factor("gebv_bits_regs_kernel<2>") == 1.92
