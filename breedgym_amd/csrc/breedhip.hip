@@ -96,10 +96,11 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
   c->half = (int32_t)((n_markers + 1) / 2);
   c->nwh = (c->half + 63) / 64;
   c->nw = (int32_t)((n_markers + 63) / 64);
-  // Long rows start on 128-byte lines.  A 100,000-marker row is 25,008 bytes: every 128-byte piece a matrix-core GEBV
-  // pass or a mask writer takes of it straddles two lines, every line is asked for twice -- configs[2]'s step at
-  // 100,352 markers (25,088-byte rows) is 30 us SHORTER than at 100,000 (long-row launch -15, finish -8, GEBV pass -5:
-  // profiles/r05_c3_markers.txt).  Rows of up to 4 KB keep the pitch their kernels were tuned at.
+  // Long rows start on 128-byte lines.  A 100,000-marker row is 25,008 bytes: every 128-byte piece the matrix-core GEBV
+  // passes take of a row straddled two lines, every line was asked for twice -- the one-trait pass over 8192 rows takes
+  // 40 us instead of 52 with rows on lines, configs[2]'s step 2-4 % less (profiles/r05_ab_pitch.txt; the mask rows keep
+  // the same pitch for one stride in the row roles, their own alignment measures nothing).  Rows of up to 4 KB keep the
+  // pitch their kernels were tuned at: the headline launch's stores do not care (profiles/r05_store_ceiling.txt).
   c->pw = c->nw > 256 ? (int32_t)round_up(c->nw, 8) : c->nw;
   c->zw = c->pw;
   c->nvec = (int32_t)(c->pitch / 16);
