@@ -38,7 +38,7 @@ def packed_host(t):
     return t.cpu().numpy().view(np.uint16)
 
 
-@pytest.mark.parametrize("M", [1, 5, 8, 9, 63, 64, 65, 100, 1000, 1001, 10000, 20000])
+@pytest.mark.parametrize("M", [1, 5, 8, 9, 63, 64, 65, 100, 1000, 1001, 10000, 16384, 16385, 16896, 20000, 32768 + 64])
 def test_pack_unpack_roundtrip(M, rng):
     N = 7
     g = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)

@@ -66,6 +66,31 @@ def test_dma_stream_issues_every_store_and_dma_unconditionally(cross_isa):
     assert any("packed_long_kernel" in n for n in checked) and any("packed_row_kernel" in n for n in checked), checked
 
 
+def test_finish_and_pack_kernels_load_without_lane_conditions(cross_isa):
+    """A load under a lane condition is a branch with a wait for the load behind it -- and `load, then select` is not
+    enough: the compiler turns a select on a loaded value with one use back into a branch.  Round 5: the finish kernels'
+    site-word reads were three cases under lane conditions (190 branches in mask_finish4_kernel, its loads one trip to
+    memory after the other: 37 us where 29 do), pack_kernel's eight loads eight trips.  Pinned on the emitted ISA: few
+    branches, wide loads of the B plane, and waits that leave loads in flight."""
+    seen = set()
+    for name, body in kernel_bodies(cross_isa):
+        br = sum("s_cbranch" in l for l in body)
+        loads = [l for l in body if re.search(r"\bglobal_load_dword", l)]
+        wait0 = sum("s_waitcnt" in l and "vmcnt(0)" in l for l in body)
+        if "mask_finish4_kernel" in name:
+            assert br <= 60, (name, br)
+            assert sum("global_load_dwordx4" in l for l in loads) >= 16, name  # plane B's string, 16 bytes per word
+            assert len(loads) >= 40 and wait0 <= 8, (name, len(loads), wait0)
+            seen.add("finish4")
+        elif "mask_finish_kernel" in name:
+            assert br <= 16 and len(loads) >= 16 and wait0 <= 4, (name, br, len(loads), wait0)
+            seen.add("finish")
+        elif "pack_kernel" in name and "packed" not in name:
+            assert len(loads) == 8 and wait0 <= 3, (name, len(loads), wait0)
+            seen.add("pack")
+    assert seen == {"finish4", "finish", "pack"}, seen
+
+
 def test_two_role_kernels_address_lds_and_memory_by_type(cross_isa):
     """The row waves' LDS copy of the digit planes (packed_stream_role, DIGLDS) is read through pointers that are LDS by
     type: no flat_* access may appear in the two-role kernels (a generic pointer the compiler could not place becomes a
