@@ -165,6 +165,13 @@ int bh_create(int device, int64_t n_markers, int64_t n_traits, const float *reco
     BH_HIP_C(hipMemcpy(c->d_alwB, alwB.data(), alwB.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   BH_HIP_C(hipMemcpy(c->d_eff, eff.data(), eff.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (n_traits > 0) {
+    std::vector<uint8_t> pos8((size_t)c->nvec, 0);
+    for (int64_t m = 0; m < n_markers; ++m)
+      if (effects[m * n_traits] > 0.0f) pos8[(size_t)(m >> 3)] |= (uint8_t)(1u << (m & 7));
+    BH_HIP_C(hipMalloc(&c->d_pos8, pos8.size()));
+    BH_HIP_C(hipMemcpy(c->d_pos8, pos8.data(), pos8.size(), hipMemcpyHostToDevice));
+  }
   {
     std::vector<double> effsum((size_t)c->effPitch, 0.0);
     for (int64_t m = 0; m < n_markers; ++m)
@@ -298,6 +305,8 @@ int bh_destroy(bh_ctx *c) {
   if (c->d_partial) (void)hipFree(c->d_partial);
   if (c->d_gsum) (void)hipFree(c->d_gsum);
   if (c->d_pool_gebv) (void)hipFree(c->d_pool_gebv);
+  if (c->d_pos8) (void)hipFree(c->d_pos8);
+  if (c->d_ohp) (void)hipFree(c->d_ohp);
   if (c->d_alwB) (void)hipFree(c->d_alwB);
   if (c->d_eff) (void)hipFree(c->d_eff);
   if (c->d_effsum) (void)hipFree(c->d_effsum);
@@ -389,6 +398,7 @@ int bh_release_scratch(bh_ctx *c) {
   drop(c->d_best, c->best_cap);
   drop(c->d_gsum, c->gsum_cap);  // (zero whenever no launch is in flight: nothing is lost)
   drop(c->d_pool_gebv, c->pool_gebv_cap);
+  drop(c->d_ohp, c->ohp_cap);
   {
     void *p = c->d_partial;
     drop(p, c->partial_cap);

@@ -100,6 +100,9 @@ struct bh_ctx {
   int64_t partial_cap = 0;       // int32 words
   void *d_gsum = nullptr;  // gebv_bits.h, GebvOut: the final cells, then one set of cells per slice group
   int64_t gsum_cap = 0;    // bytes
+  uint8_t *d_pos8 = nullptr;    // (nvec) bit i: the first trait's effect of marker 8 v + i is positive (index_kernels.h)
+  void *d_ohp = nullptr;        // bh_optimal_haploid: the haploids as bit-plane rows, then the block of every marker
+  int64_t ohp_cap = 0;
   void *d_pool_gebv = nullptr;  // gebv_bits: the GEBV of a pool's rows, on its way through an index (gebv.hip)
   int64_t pool_gebv_cap = 0;
   // top-k scratch

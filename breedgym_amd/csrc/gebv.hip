@@ -242,6 +242,43 @@ int bh_optimal_haploid(bh_ctx *c, const uint8_t *d_pop, int64_t n_rows, const in
   if (n_blocks > 0 && !d_block_start) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: blocks without offsets");
   if (c->T == 0) return fail(BH_ERR_BAD_ARG, "bh_optimal_haploid: the context has no traits");
   if (n_rows > 0x3FFFFFFF || n_blocks > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "bh_optimal_haploid: too large");
+  // the stream (index_kernels.h, ohp_stream_kernel) where the blocks' cells fit a workgroup's LDS: the haploid as bits, its
+  // value by the matrix-core GEBV pass over them
+  const int ohp_rows = bh::kOhpRows * 20 * n_blocks <= bh::kOhpLdsBytes ? bh::kOhpRows : 20 * n_blocks <= bh::kOhpLdsBytes ? 1 : 0;
+  if (ohp_rows > 0) {
+    const int64_t ppitch = (int64_t)16 * c->pw, planes_bytes = d_ohv ? (n_rows * ppitch + 255) / 256 * 256 : 0;
+    const int64_t n_blk = (int64_t)8 * c->nvec, blk_bytes = n_blocks > 0 ? n_blk * 2 : 0;
+    if (planes_bytes + blk_bytes > 0)
+      if (int rc = ensure_scratch(c, &c->d_ohp, &c->ohp_cap, planes_bytes + blk_bytes)) return rc;
+    bh::OhpParams p{};
+    p.pop = d_pop;
+    p.pos8 = c->d_pos8;
+    p.effsum = c->d_effsum;
+    p.planes = d_ohv ? static_cast<uint16_t *>(c->d_ohp) : nullptr;
+    p.blk = n_blocks > 0 ? reinterpret_cast<const uint16_t *>(static_cast<uint8_t *>(c->d_ohp) + planes_bytes) : nullptr;
+    p.ohp = d_ohp;
+    p.pitch = c->pitch;
+    p.M = (int32_t)c->M;
+    p.nvec = c->nvec;
+    p.nvp = 8 * c->pw;
+    p.n_rows = (int32_t)n_rows;
+    p.n_blocks = (int32_t)n_blocks;
+    if (n_blocks > 0) {
+      hipLaunchKernelGGL(bh::ohp_blocks_kernel, dim3((unsigned)((n_blk + 255) / 256)), dim3(256), 0, c->stream, d_block_start,
+                         (int)n_blocks, (int)c->M, (int)n_blk, const_cast<uint16_t *>(p.blk));
+      BH_HIP(hipGetLastError());
+    }
+    const size_t lds = (size_t)ohp_rows * 20 * n_blocks;
+    const unsigned grid = (unsigned)((n_rows + ohp_rows - 1) / ohp_rows);
+    if (ohp_rows == 1)
+      hipLaunchKernelGGL(bh::ohp_stream_kernel<1>, dim3(grid), dim3(256), lds, c->stream, p);
+    else
+      hipLaunchKernelGGL(bh::ohp_stream_kernel<bh::kOhpRows>, dim3(grid), dim3(256), lds, c->stream, p);
+    BH_HIP(hipGetLastError());
+    if (d_ohv) return gebv_bits(c, p.planes, n_rows, nullptr, n_rows, d_ohv);
+    return BH_OK;
+  }
+  // ... beyond (more than ~3200 blocks): a wave per row, block by block
   for (int t0 = 0; t0 < c->T; t0 += bh::kOhvTraits) {
     bh::OhvParams p{};
     p.pop = d_pop;

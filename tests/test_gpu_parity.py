@@ -545,6 +545,30 @@ def test_optimal_haploid_kernel(T, B, rng):
     assert torch.equal(only_v, ohv)
 
 
+@pytest.mark.parametrize("M,N,T,B", [(20000, 70, 1, None), (20000, 70, 3, 5), (16392, 33, 1, 7), (1001, 9, 2, 40), (2500, 5, 1, 700), (4001, 5, 1, 1200)])
+def test_optimal_haploid_stream_at_size(M, N, T, B, rng):
+    """The streaming form of bh_optimal_haploid (index_kernels.h, ohp_stream_kernel: the haploid as bits, its value by the
+    matrix-core GEBV pass) on long rows, on ragged ones, with blocks that end inside a 16-byte vector, with one row per
+    workgroup (2,100 blocks) and beyond what a workgroup's LDS holds (3,600 blocks: the wave-per-row kernel) -- against the C restatement."""
+    from oracle import numpy_oracle as no
+
+    pop = rng.integers(0, 2, (N, M, 2), dtype=np.uint8)
+    pop[1] = pop[0]  # equal rows, and a row whose two haplotypes are equal (every block a tie: the first one wins)
+    pop[2, :, 1] = pop[2, :, 0]
+    eff = rng.laplace(0, 6, (M, T)).astype(np.float32)
+    eff[::7] = 0.0
+    eng = make_engine(np.full(M, 0.01, np.float32), eff)
+    lens = [M // 3, 5, M - M // 3 - 5]
+    bs = None if B is None else no.block_starts(B, lens)
+    dbs = None if bs is None else torch.from_numpy(bs).to(eng.device)
+    ohp, ohv = eng.optimal_haploid(eng.upload_population(pop), dbs)
+    ref_p, ref_v = co.optimal_haploid(pop, eff, bs)
+    assert np.array_equal(ohp.cpu().numpy(), ref_p)
+    assert np.allclose(ohv.cpu().numpy(), ref_v, rtol=1e-6, atol=1e-4)
+    assert torch.equal(eng.optimal_haploid(eng.upload_population(pop), dbs, want_pop=False)[1], ohv)
+    assert torch.equal(eng.optimal_haploid(eng.upload_population(pop), dbs, want_value=False)[0], ohp)
+
+
 def test_index_functions_on_device(rng):
     """OHV with the poor-yield mask and the greedy OPV mask end to end on the GPU == NumPy restatement."""
     from breedgym_amd import Simulator
