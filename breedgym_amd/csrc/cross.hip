@@ -420,7 +420,8 @@ int mutate_rows(bh_ctx *c, uint32_t key0, uint32_t key1, int64_t nkeys, KeyWindo
     q.F = sp.F + s0 * fpitch;
     // stream s0 + y: advance the key index by s0 streams (s0 is even: gamete parity is kept)
     q.key_offset = (uint32_t)(kw.off + (dh ? s0 : s0 / 2));
-    hipLaunchKernelGGL(bh::mutation_sites_kernel, dim3((unsigned)std::min(64, (wl + 3) / 4), (unsigned)ns), dim3(256), 0,
+    // (a wave takes two chunks per turn; few workgroups per stream: each starts with the three Threefry calls of its key)
+    hipLaunchKernelGGL(bh::mutation_sites_kernel, dim3((unsigned)std::min(8, (wl + 7) / 8), (unsigned)ns), dim3(256), 0,
                        c->stream, q);
     BH_HIP(hipGetLastError());
   }
@@ -438,10 +439,11 @@ int mutate_rows(bh_ctx *c, uint32_t key0, uint32_t key1, int64_t nkeys, KeyWindo
   ap.ppitch = 8 * (int64_t)c->pw;
   ap.outb = d_out_bytes;
   ap.bpitch = c->pitch;
-  const int64_t threads = rows * ((c->M + 7) / 8);
-  if (threads > 0) {
-    if ((threads + 255) / 256 > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "mutation: too many rows for one launch");
-    hipLaunchKernelGGL(bh::mutation_apply_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, ap);
+  const int64_t threads = streams * 2 * wl;  // one per flip word
+  if (threads > 0 && rows > 0) {
+    if ((threads + 255) / 256 > 0x7FFFFFFF) return fail(BH_ERR_UNSUPPORTED, "mutation: too many crosses for one launch");
+    hipLaunchKernelGGL(bh::mutation_apply_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, ap,
+                       (int32_t)streams);
     BH_HIP(hipGetLastError());
   }
   return BH_OK;

@@ -45,23 +45,36 @@ __global__ __launch_bounds__(256) void mutation_sites_kernel(MutationParams p) {
     mk = {threefry2x32(g0, g1, 0u, 2u).y, threefry2x32(g0, g1, 1u, 3u).y};  // words 2, 3 of threefry_iota(gk, 4)
   }
   uint64_t *F = p.F + (int64_t)s * p.fpitch;
-  for (int chunk = blockIdx.x * 4 + wid; chunk < p.wl; chunk += gridDim.x * 4) {
-    const uint32_t i = (uint32_t)chunk * 64u + lane;
+  // the draws: Threefry and little else (as many calls as the crossover masks of the same crosses take) -- two chunks of
+  // 64 draws per wave and turn through the hand-placed two-chain block of threefry.h, the key schedule in scalar
+  // registers (round 5: 2048 x 2 x 100k draws took 920 us with one chain of the compiler's stream per lane)
+  const uint32_t k0 = __builtin_amdgcn_readfirstlane(mk.x), k1 = __builtin_amdgcn_readfirstlane(mk.y);
+  const KeySched ks = key_sched(k0, k1);
+  for (int chunk = (blockIdx.x * 4 + wid) * 2; chunk < p.wl; chunk += gridDim.x * 8) {
+    const bool two = chunk + 1 < p.wl;  // (uniform; a wave whose second chunk does not exist redoes its first)
+    const uint32_t ia = (uint32_t)chunk * 64u + lane, ib = two ? ia + 64u : ia;
+    uint64_t wa0, wa1, wb0 = 0, wb1 = 0;
     if (p.layout == LAYOUT_PARTITIONABLE) {
-      const bool flip = i < (uint32_t)p.M && (bits_word_partitionable(mk.x, mk.y, i) >> 9) < p.thr;
-      const uint64_t w = __ballot(flip);
-      if (lane == 0) {
-        F[chunk] = w;
-        F[p.wl + chunk] = 0;  // no second half in this layout
-      }
+      uint32_t a0 = k0, a1 = ia + k1, b0 = k0, b1 = ib + k1;  // random_bits(mk, M)[i] = x ^ y of threefry(mk, (0, i))
+      threefry2x32_x2(ks, a0, a1, b0, b1);
+      wa0 = __ballot(ia < (uint32_t)p.M && ((a0 ^ a1) >> 9) < p.thr);
+      wa1 = __ballot(ib < (uint32_t)p.M && ((b0 ^ b1) >> 9) < p.thr);  // (no second half in this layout: wb = 0)
     } else {
-      const uint32_t j = i + (uint32_t)p.half;
-      const u32x2 o = threefry2x32(mk.x, mk.y, i, j < (uint32_t)p.M ? j : 0u);  // the pad counter of an odd M is 0
-      const uint64_t wa = __ballot(i < (uint32_t)p.half && (o.x >> 9) < p.thr);
-      const uint64_t wb = __ballot(j < (uint32_t)p.M && (o.y >> 9) < p.thr);
-      if (lane == 0) {
-        F[chunk] = wa;
-        F[p.wl + chunk] = wb;
+      const uint32_t ja = ia + (uint32_t)p.half, jb = ib + (uint32_t)p.half;
+      uint32_t a0 = ia + k0, a1 = (ja < (uint32_t)p.M ? ja : 0u) + k1;  // the pad counter of an odd M is 0
+      uint32_t b0 = ib + k0, b1 = (jb < (uint32_t)p.M ? jb : 0u) + k1;
+      threefry2x32_x2(ks, a0, a1, b0, b1);
+      wa0 = __ballot(ia < (uint32_t)p.half && (a0 >> 9) < p.thr);
+      wb0 = __ballot(ja < (uint32_t)p.M && (a1 >> 9) < p.thr);
+      wa1 = __ballot(ib < (uint32_t)p.half && (b0 >> 9) < p.thr);
+      wb1 = __ballot(jb < (uint32_t)p.M && (b1 >> 9) < p.thr);
+    }
+    if (lane == 0) {
+      F[chunk] = wa0;
+      F[p.wl + chunk] = wb0;
+      if (two) {
+        F[chunk + 1] = wa1;
+        F[p.wl + chunk + 1] = wb1;
       }
     }
   }
@@ -80,42 +93,43 @@ struct MutationApplyParams {
   int64_t bpitch;
 };
 
-// the flips of markers [m0, m0 + 8) of one stream; m0 a multiple of 8
-__device__ __forceinline__ uint32_t mutation_flips8(const uint64_t *F, int32_t m0, int32_t half, int32_t wl) {
-  const uint8_t *lo = reinterpret_cast<const uint8_t *>(F), *hi = reinterpret_cast<const uint8_t *>(F + wl);
-  auto window = [](const uint8_t *a, int32_t bit) -> uint32_t {
-    const uint32_t v = (uint32_t)a[bit >> 3] | ((uint32_t)a[(bit >> 3) + 1] << 8);
-    return (v >> (bit & 7)) & 0xFFu;
-  };
-  uint32_t f = 0;
-  if (m0 < half) f = window(lo, m0);  // bits at and past `half` are zero there
-  if (m0 + 8 > half) f |= m0 >= half ? window(hi, m0 - half) : (window(hi, 0) << (half - m0)) & 0xFFu;
-  return f;
-}
-
-__device__ __forceinline__ uint32_t spread8(uint32_t f) {  // bit k -> bit 2k
-  f = (f | (f << 4)) & 0x0F0Fu;
-  f = (f | (f << 2)) & 0x3333u;
-  return (f | (f << 1)) & 0x5555u;
-}
-
-// one thread per (row, 8 markers)
-__global__ __launch_bounds__(256) void mutation_apply_kernel(MutationApplyParams p) {
-  const int32_t nw8 = (p.M + 7) >> 3;
+// One thread per 64-bit flip word of a stream: almost all of them are zero (p = 1e-4: ten flips per 100k-marker
+// gamete), and a thread whose word is zero is done after one load.  A set bit is a marker of one gamete of one cross:
+// it flips that allele in every offspring row that uses the cross's streams (with shared keys: one row per env).  The
+// two gametes of a cross (and the two halves of a row's markers) meet in the same 16-bit bit-plane words from
+// different threads: the bit planes are flipped with 32-bit atomic XORs; in the byte layout every (marker, allele) is
+// a byte of its own.  (Round 5: this replaces a thread per (ROW, eight markers) -- 102 M threads at 8192 x 100k, each
+// reading its window of flip bits: 274 us; by flip words the same work is 6.4 M threads.)
+__global__ __launch_bounds__(256) void mutation_apply_kernel(MutationApplyParams p, int32_t n_streams) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)p.n_rows * nw8) return;
-  const int32_t row = (int32_t)(t / nw8), w = (int32_t)(t - (int64_t)row * nw8);
-  const int32_t b = p.shared ? row % p.n_out : row;
-  const uint64_t *F0 = p.F + (int64_t)(p.dh ? b : 2 * b) * p.fpitch;
-  const uint32_t f0 = mutation_flips8(F0, 8 * w, p.half, p.wl);
-  const uint32_t f1 = p.dh ? f0 : mutation_flips8(F0 + p.fpitch, 8 * w, p.half, p.wl);
-  if ((f0 | f1) == 0) return;
-  if (p.outp) p.outp[(int64_t)row * p.ppitch + w] ^= (uint16_t)(spread8(f0) | (spread8(f1) << 1));
-  if (p.outb) {
-    uint8_t *o = p.outb + (int64_t)row * p.bpitch + 16 * (int64_t)w;
-    for (int k = 0; k < 8; ++k) {
-      if ((f0 >> k) & 1u) o[2 * k] ^= 1;
-      if ((f1 >> k) & 1u) o[2 * k + 1] ^= 1;
+  const int32_t per = 2 * p.wl;
+  if (t >= (int64_t)n_streams * per) return;
+  const int32_t s = (int32_t)(t / per), q = (int32_t)(t - (int64_t)s * per);
+  uint64_t w = p.F[(int64_t)s * p.fpitch + q];
+  if (w == 0) return;
+  const int32_t b = p.dh ? s : s >> 1, g = p.dh ? 0 : (s & 1);
+  const int32_t m0 = q < p.wl ? 64 * q : p.half + 64 * (q - p.wl);
+  while (w) {
+    const int32_t m = m0 + __builtin_ctzll(w);
+    w &= w - 1;
+    if (m >= p.M) break;  // (the draws stop at M: nothing is set there)
+    const uint32_t bits = (p.dh ? 3u : 1u << g) << (2 * (m & 7));
+    for (int32_t row = b; row < p.n_rows; row += p.n_out) {  // the rows of the cross: one, or one per env (shared keys)
+      if (p.outp) {
+        uint16_t *hw = p.outp + (int64_t)row * p.ppitch + (m >> 3);
+        uint32_t *wd = reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>(hw) & ~(uintptr_t)3);
+        atomicXor(wd, bits << ((reinterpret_cast<uintptr_t>(hw) & 2) ? 16 : 0));
+      }
+      if (p.outb) {
+        uint8_t *o = p.outb + (int64_t)row * p.bpitch + 2 * (int64_t)m;
+        if (p.dh) {
+          o[0] ^= 1;
+          o[1] ^= 1;
+        } else {
+          o[g] ^= 1;
+        }
+      }
+      if (!p.shared) break;
     }
   }
 }
