@@ -558,7 +558,8 @@ GatherPlan plan_gather(const bh_ctx *c, const uint16_t *d_src, int64_t src_rows,
   g.fused = d_gebv && c->T <= kMaxFusedTraits && !g.mfma_after;
   p.tcount = g.fused ? (int32_t)c->T : 0;
   g.turns = (p.tcount == 0 && d_out_packed) ? long_row_turns(c, n_rows) : 0;
-  p.seq = g.turns;
+  // (long rows without GEBV in the stream: the pipelined stream, not the plain loop -- one row per wave unless in turns)
+  p.seq = g.turns > 1 ? g.turns : (p.tcount == 0 && d_out_packed && d_out_bytes && c->M > 16384 ? 1 : 0);
   return g;
 }
 
@@ -580,7 +581,25 @@ int run_gather(bh_ctx *c, const GatherPlan &g, const uint16_t *d_src, int64_t sr
     BH_HIP(hipGetLastError());
     return BH_OK;
   }
-  if (p.tcount > 0 || p.outp || p.outb) {
+  if (!p.outp && p.outb && p.tcount == 0) {
+    // byte rows out and nothing else in the stream (unpack; a lazy env's observation): rows cut over waves
+    bh::ExpandParams q{};
+    q.src = d_src;
+    q.idx = d_idx;
+    q.dst = p.outb;
+    q.pitch = c->pitch;
+    q.nvec = c->nvec;
+    q.nvp = 8 * c->pw;
+    q.n_pool = (int32_t)src_rows;
+    q.n_rows = (int32_t)n_rows;
+    q.nt = p.obs_nt;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {  // grid.y holds 65535
+      q.row0 = (int32_t)r0;
+      hipLaunchKernelGGL(bh::packed_expand_kernel, dim3((unsigned)((q.nvec + 2047) / 2048), (unsigned)std::min<int64_t>(65535, n_rows - r0)),
+                         dim3(256), 0, c->stream, q);
+      BH_HIP(hipGetLastError());
+    }
+  } else if (p.tcount > 0 || p.outp || p.outb) {
     if (int rc = g.turns > 1 ? launch_prow_r<bh::MODE_GATHER, kRowsPerWaveLong>(c, p, 0)
                              : launch_prow_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount)))
       return rc;
@@ -773,7 +792,10 @@ static int cross_impl(bh_ctx *c, const char *who, bool packed, const void *d_poo
       p.reward_pitch = reward_pitch;
       p.n_envs = (int32_t)n_envs;
       const int turns = (tcount == 0 && (!run_ahead || mw == 4)) ? long_row_turns(c, rows) : 0;
-      p.seq = turns;
+      // (long rows without GEBV in the stream -- three traits and more: the matrix-core pass follows -- take the pipelined
+      // stream, not the plain loop, also where they are too few for turns -- where the byte rows are written: 4 x 512 x 100k 243 ->
+      // 208 us with them, 143 -> 151 without)
+      p.seq = turns > 1 ? turns : (tcount == 0 && d_out_bytes && c->M > 16384 && (!run_ahead || mw == 4) ? 1 : 0);
       if (run_ahead) {
         if (mw == 1)
           rc = wide ? launch_pcross_mw<1, kRowsPerWavePacked>(c, p, mp, tt_for(tcount))

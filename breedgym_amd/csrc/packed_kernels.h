@@ -544,8 +544,8 @@ __global__ __launch_bounds__(256) void packed_row_kernel(const PackedParams p) {
   }
   if constexpr (TT <= 2) {
     // packed rows out (reset's founder gather, a cross without run-ahead): the pipelined stream; without
-    // GEBV only where the host asks for it (p.seq > 1: long rows in turns)
-    if (p.outp && (TT > 0 || p.seq > 1)) {
+    // GEBV only where the host asks for it (p.seq >= 1: long rows, in turns when there are many)
+    if (p.outp && (TT > 0 || p.seq >= 1)) {
       // with GEBV in the stream: two vectors per lane and trip when the observation is written too (-2.5 % at
       // 16 x 256 x 10k), one otherwise
       if (p.outb && p.obs_nt)
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(512) void packed_cross_kernel(const PackedParams rp
   if (wave < 4) {
     if (block < rp.n_blocks) {
       if constexpr (TT <= 2 && MW == 4) {
-        if (TT > 0 || rp.seq > 1) {
+        if (TT > 0 || rp.seq >= 1) {  // (without GEBV: long rows only, cross.hip -- short ones keep the plain loop)
           if constexpr (TT == 1) {
             if (rp.dig_lds && rp.outb && !rp.obs_nt) {
               packed_stream_role<TT, MODE_CROSS, R, true, kShortRowVectors, false, 4, true>(
@@ -731,6 +731,37 @@ __global__ __launch_bounds__(256) void packed_copy_rows_kernel(const CopyRowsPar
 #pragma unroll
   for (int u = 0; u < 4; ++u)
     if (piece0 + 64 * u < n_pieces) d[piece0 + 64 * u] = t[u];
+}
+
+// packed rows (through an index) -> byte-layout rows and nothing else: `unpack`, the observation of a lazy env.  A row
+// cut over many waves like pack_kernel's: as a gather of the row roles -- a wave per row, 196 trips of 2-byte words for a
+// 100k-marker row -- 2048 rows took 181 us where packing them takes 87.  grid (ceil(nvec / 2048), rows).
+struct ExpandParams {
+  const uint16_t *src;  // (n_pool, nvp)
+  const int32_t *idx;   // (n_rows) or null (= identity)
+  uint8_t *dst;         // (n_rows, pitch)
+  int64_t pitch;
+  int32_t nvec, nvp, n_pool, n_rows, row0, nt;
+};
+__global__ __launch_bounds__(256) void packed_expand_kernel(const ExpandParams p) {
+  const int row = p.row0 + blockIdx.y, lane = threadIdx.x & 63;
+  const int v0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 512 + lane;
+  if (v0 - lane >= p.nvec) return;
+  const uint16_t *s = p.src + (int64_t)(p.idx ? norm_index(p.idx[row], p.n_pool) : row) * p.nvp;
+  char *d = reinterpret_cast<char *>(p.dst + (int64_t)row * p.pitch);
+  uint32_t w[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w[u] = s[min(v0 + 64 * u, p.nvec - 1)];  // (every lane loads)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int v = v0 + 64 * u;
+    if (v >= p.nvec) continue;
+    const uint4 x = expand_vector(w[u]);
+    if (p.nt)
+      store_obs(d + 16 * (int64_t)v, x);
+    else
+      *reinterpret_cast<uint4 *>(d + 16 * (int64_t)v) = x;
+  }
 }
 
 // byte-layout rows -> packed rows.  One lane per 16-byte vector.
