@@ -1036,7 +1036,10 @@ int bh_gather(bh_ctx *c, const uint8_t *d_src, int64_t src_rows, const int32_t *
   p.gebv = d_gebv;
   p.n_pool = (int32_t)src_rows;
   p.n_rows = (int32_t)n_rows;
-  const bool fused = d_gebv && c->T <= kMaxFusedTraits && !use_mfma_gebv(c, n_rows);
+  // (large gathers: the rows first, then the one-pass matrix-core GEBV over them -- 2048 x 100k x 1: 145 + 74 us against
+  // 256 us with the f64 GEBV in the gather's stream, profiles/r05_scan_ops.txt)
+  const bool fused = d_gebv && c->T <= kMaxFusedTraits && !use_mfma_gebv(c, n_rows) &&
+                     !(use_bits_gebv(c, n_rows) && n_rows * c->M >= kGebvViaPlanesMin);
   p.t0 = 0;
   p.tcount = fused ? (int32_t)c->T : 0;
   if (int rc = launch_row_mode<bh::MODE_GATHER>(c, p, tt_for(p.tcount))) return rc;
