@@ -661,6 +661,8 @@ extern "C" {
 //                             lane mask role) + mask_finish_kernel;  else packed_cross_kernel<TT, 4, R> (a deferred
 //                             founder draw of <= 1024 rows rides on it);  R = 2 rows per wave from 4096 rows on.
 //                             no run_ahead: packed_row_kernel<TT, MODE_CROSS, R> (long rows in turns: its DMA stream)
+//                             rows of M > 16384 without fused GEBV whose byte rows are written take the pipelined
+//                             stream (seq = 1) where they are too few for turns, not the plain loop
 //   the launch, byte layout   run_ahead: cross_kernel<TT, mw, R, LONG>;  else row_kernel<W, TT, MODE_CROSS, R, LONG>
 //                             (W = 4 waves per row for fewer than 2048 rows of more than 16384 markers)
 //   behind the launch         mutation: mutation_sites_kernel + mutation_apply_kernel;  GEBV passes as above;  reward:
