@@ -182,3 +182,17 @@ def test_population_sharded_four_ranks():
     its redo -- the same assertions as with two ranks, row for row against one device's generation."""
     out = _run(_pop_sharded_worker, world=4, extra=("bits",), join_s=180)
     assert out[0][1] == out[1][1] == out[2][1] == out[3][1]
+
+
+@pytest.mark.timeout(300)
+def test_population_sharded_eight_ranks():
+    """configs[3]'s own rank count: eight shards of five rows, winners from most of them, fewer local rows than k."""
+    out = _run(_pop_sharded_worker, world=8, extra=("bits",), join_s=240)
+    assert all(o[1] == out[0][1] for o in out)
+
+
+@pytest.mark.timeout(300)
+def test_env_sharded_eight_ranks():
+    """The width the driver's scaling run ends at: eight env windows of one vector env of 24."""
+    out = _run(_env_sharded_worker, world=8, extra=("shared",), join_s=240)
+    assert all(o[1] == out[0][1] and o[2] == out[0][2] for o in out)
