@@ -91,8 +91,9 @@ def _env_sharded_worker(rank, world, port, q, env_rng="shared", engine_kind="ora
     dist.destroy_process_group()
 
 
-def _pop_sharded_worker(rank, world, port, q, storage="bytes", engine_kind="oracle"):
+def _pop_sharded_worker(rank, world, port, q, storage="bytes", engine_kind="oracle", shape=None):
     _setup(rank, world, port)
+    N, M, K = shape or (globals()["N"], globals()["M"], 9)  # (individuals, markers, winners per generation)
 
     from breedgym_amd.simulator import Simulator
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
@@ -112,22 +113,22 @@ def _pop_sharded_worker(rank, world, port, q, storage="bytes", engine_kind="orac
     for k in (1, 5, 13, n_local, n_local + 4):
         got = sp.global_topk(torch.from_numpy(scores_all[mine].copy()), k)
         assert np.array_equal(got.cpu().numpy(), co.topk(scores_all, k)), k
-    best = sp.global_topk(sp.gebv()[:, 0], 9)
+    best = sp.global_topk(sp.gebv()[:, 0], K)
     parents = sp.gather_rows(best)
-    assert np.array_equal(parents.cpu().numpy()[:, : 2 * M].reshape(9, M, 2), geno[best.cpu().numpy()])
+    assert np.array_equal(parents.cpu().numpy()[:, : 2 * M].reshape(K, M, 2), geno[best.cpu().numpy()])
     # WORLD-SIZE INVARIANCE over four generations: the same key on every rank, every rank's rows of one global
     # pair table -> the generation one device would compute for the whole population, row for row
     key = co.key_from_seed(100).copy()
     ref, refkey = geno, co.key_from_seed(100)
     for gen in range(4):
-        pairs_global = np.random.default_rng(gen).integers(0, 9, (N, 2), dtype=np.int32)
+        pairs_global = np.random.default_rng(gen).integers(0, K, (N, 2), dtype=np.int32)
         if gen == 0:
             assert sp._cap_hint is None  # the first generation sizes its blocks exactly
         elif gen == 2:
             sp._cap_hint = 1  # a guess that is too small: the generation is redone with the exact size, same results
-        g = sp.select_and_cross(9, torch.from_numpy(pairs_global[mine]), key)
+        g = sp.select_and_cross(K, torch.from_numpy(pairs_global[mine]), key)
         assert sp.redone == (1 if gen >= 2 else 0) and sp._cap_hint >= 1
-        true_best = co.topk(co.gebv(ref, gm.marker_effects)[:, 0], 9)
+        true_best = co.topk(co.gebv(ref, gm.marker_effects)[:, 0], K)
         out, refkey = co.cross(ref[true_best][None], pairs_global[None], gm.recombination_vec, refkey, 1)
         ref = out[0]
         assert np.array_equal(sp.rows.cpu().numpy()[:, : 2 * M].reshape(n_local, M, 2), ref[mine]), (rank, gen)
@@ -196,3 +197,12 @@ def test_env_sharded_eight_ranks():
     """The width the driver's scaling run ends at: eight env windows of one vector env of 24."""
     out = _run(_env_sharded_worker, world=8, extra=("shared",), join_s=240)
     assert all(o[1] == out[0][1] and o[2] == out[0][2] for o in out)
+
+
+@pytest.mark.timeout(300)
+def test_population_sharded_two_ranks_longer_rows():
+    """Rows beyond one 16-byte-granular KB (M = 4,160: bit-plane rows of 1,040 bytes), more winners than a shard has rows
+    to give on average (k = 24 of 2 x 32), both storages' shared code path through the shape parameter the GPU suite
+    uses for configs[3]'s row length."""
+    out = _run(_pop_sharded_worker, extra=("bits", "oracle", (64, 4160, 24)), join_s=240)
+    assert out[0][1] == out[1][1]

@@ -38,6 +38,16 @@ def test_population_sharded_four_ranks_on_one_gpu():
     assert out[0][1] == out[1][1] == out[2][1] == out[3][1]
 
 
+@pytest.mark.timeout(900)
+def test_population_sharded_two_ranks_at_configs3_row_length():
+    """configs[3]'s rows (100,000 markers: 25,088-byte bit-plane rows on whole lines, the long-row launch with independent
+    keys, the matrix-core GEBV pass, radix-select top-k) in two shards of 1,024, k = n // 10 winners per generation from
+    both shards, four generations with a redone one: every rank's rows == the rows one device computes for the whole
+    population (the C oracle's), byte for byte -- the toy shape's assertions where the kernels are the ones configs[3] runs."""
+    out = _run(_pop_sharded_worker, extra=("bits", "hip", (2048, 100_000, 204)), join_s=800)
+    assert out[0][1] == out[1][1]
+
+
 @pytest.mark.timeout(600)
 def test_env_sharded_three_ranks_on_one_gpu():
     out = _run(_env_sharded_worker, world=3, extra=("shared", "hip"), join_s=420)
