@@ -44,8 +44,10 @@ def _engine_kw(engine_kind, gm):
     return {"engine": OracleEngine(gm.recombination_vec, gm.marker_effects)}
 
 
-def _env_sharded_worker(rank, world, port, q, env_rng="shared", engine_kind="oracle"):
+def _env_sharded_worker(rank, world, port, q, env_rng="shared", engine_kind="oracle", shape=None):
     _setup(rank, world, port)
+    # (germplasm rows, markers, envs per rank, individuals per env, selection k, selection crosses)
+    N, M, EL, n, K, NC = shape or (globals()["N"], globals()["M"], 3, 8, 4, 5)
 
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
     from breedgym_amd.vector import SelectionScores
@@ -54,20 +56,20 @@ def _env_sharded_worker(rank, world, port, q, env_rng="shared", engine_kind="ora
 
     gm = synthetic_genetic_map(M, n_chr=2, seed=1)
     geno = synthetic_genotypes(N, M, seed=2)
-    E = 3 * world
-    env = DistributedBreedGym(3, geno, individual_per_gen=8, genetic_map=gm, reward_shaping=True, env_rng=env_rng,
+    E = EL * world
+    env = DistributedBreedGym(EL, geno, individual_per_gen=n, genetic_map=gm, reward_shaping=True, env_rng=env_rng,
                               **_engine_kw(engine_kind, gm))
-    assert env.num_envs == E and env.local_slice() == slice(3 * rank, 3 * rank + 3)
+    assert env.num_envs == E and env.local_slice() == slice(EL * rank, EL * rank + EL)
     pop, _ = env.reset(seed=10)  # the same seed on every rank
     # WORLD-SIZE INVARIANCE: what ONE VecBreedGym of 3 * world envs computes, this rank's envs of it
     mode = 0 if env_rng == "shared" else 1
-    f, env_key = co.founders(co.key_from_seed(10), E, N, 8)
+    f, env_key = co.founders(co.key_from_seed(10), E, N, n)
     ref = geno.view(np.uint8)[f]
     assert np.array_equal(np.asarray(pop).view(np.uint8), ref[env.local_slice()])
     key = co.key_from_seed(10)
     arng = np.random.default_rng(0)
     for step in range(3):
-        global_actions = arng.integers(0, 8, (E, 8, 2), dtype=np.int32)
+        global_actions = arng.integers(0, n, (E, n, 2), dtype=np.int32)
         new_pop, r, ter, tru, infos = env.step(global_actions)  # takes its own slice
         ref, key = co.cross(ref, global_actions, gm.recombination_vec, key, mode)
         assert np.array_equal(np.asarray(new_pop).view(np.uint8), ref[env.local_slice()]), (rank, step)
@@ -78,13 +80,13 @@ def _env_sharded_worker(rank, world, port, q, env_rng="shared", engine_kind="ora
     best = env.best_reward(r)
     assert abs(best - allr.max()) < 1e-6
     g = env.all_gather(infos["GEBV"])
-    assert g.shape == (E, 8, 1)
+    assert g.shape == (E, n, 1)
     # the selection wrapper draws its pair shuffles through the same env window
-    w = SelectionScores(env.env, k=4, n_crosses=5)
+    w = SelectionScores(env.env, k=K, n_crosses=NC)
     scores = co.gebv(ref, gm.marker_effects)[..., 0]
     low = w._convert_actions(scores[env.local_slice()])
     low = low.cpu().numpy() if isinstance(low, torch.Tensor) else np.asarray(low)
-    ref_low, ref_env_key = co.selection_actions(scores, 4, 5, env_key)
+    ref_low, ref_env_key = co.selection_actions(scores, K, NC, env_key)
     assert np.array_equal(low, ref_low[env.local_slice()]) and np.array_equal(env.env.random_key, ref_env_key)
     q.put((rank, allr.tolist(), best))
     dist.barrier()

@@ -48,6 +48,15 @@ def test_population_sharded_two_ranks_at_configs3_row_length():
     assert out[0][1] == out[1][1]
 
 
+@pytest.mark.timeout(900)
+def test_env_sharded_two_ranks_at_the_headline_shape():
+    """What ``bench.py --gpus 2`` runs per rank -- 16 envs x 256 x 10k out of a 370-row germplasm through the two-role
+    launch, bit-plane state, the env window (rank x 16 of 32) -- checked where the toy shape's assertions are: founders,
+    three steps and the selection wrapper's shuffles byte for byte against ONE 32-env oracle run."""
+    out = _run(_env_sharded_worker, extra=("shared", "hip", (370, 10_000, 16, 256, 25, 256)), join_s=800)
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+
+
 @pytest.mark.timeout(600)
 def test_env_sharded_three_ranks_on_one_gpu():
     out = _run(_env_sharded_worker, world=3, extra=("shared", "hip"), join_s=420)
