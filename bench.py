@@ -527,9 +527,10 @@ def bench_c5(reps):
     }
 
 
-def population_generation(steps, warmup, rank, world, local_rank, use_dist, barrier, all_reduce=None, seen=None):
+def population_generation(steps, warmup, rank, world, local_rank, use_dist, barrier, all_reduce=None, seen=None, n_local=8192):
     """BASELINE configs[3]: one population sharded row-wise, 8192 x 100k per rank, k = n_total // 10.  Returns the
-    JSON line of the population mode (rank 0; None elsewhere)."""
+    JSON line of the population mode (rank 0; None elsewhere).  `n_local`: rows per rank (65,536 with one rank = the
+    whole population of configs[3] on one device)."""
     import torch
     import torch.distributed as dist
 
@@ -537,7 +538,7 @@ def population_generation(steps, warmup, rank, world, local_rank, use_dist, barr
     from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
     from breedgym_amd.vector.distributed import ShardedPopulation
 
-    n_local, M = 8192, 100_000
+    M = 100_000
     n_total = n_local * world
     k = n_total // 10
     gm = synthetic_genetic_map(M, n_chr=21, n_traits=1, seed=1)
@@ -546,7 +547,7 @@ def population_generation(steps, warmup, rank, world, local_rank, use_dist, barr
     base = synthetic_genotypes(512, M, seed=10 + rank)  # a rank's shard: 8192 rows drawn from 512 distinct ones
     rows = eng.upload_population(base)
     pick = torch.from_numpy(np.random.default_rng(rank).integers(0, 512, n_local, dtype=np.int32)).to(eng.device)
-    shard = eng.empty_population(n_local)
+    shard = eng.empty_population(n_local)  # (byte rows: 13.1 GB where one rank holds all 65,536)
     eng.gather(rows, pick, shard)
     del rows
     sp = ShardedPopulation(sim, shard, storage="bits")
@@ -577,12 +578,12 @@ def population_generation(steps, warmup, rank, world, local_rank, use_dist, barr
     return {
         **({"distributed": distributed} if distributed else {}),
         "generations_redone": sp.redone,  # winners' blocks guessed too small (vector/distributed.py): 0 in a steady run
-        "metric": "crosses/sec (population-sharded generation: top-k GEBV selection + crosses) at 8192 x 100k markers per GPU",
+        "metric": f"crosses/sec (population-sharded generation: top-k GEBV selection + crosses) at {n_local} x 100k markers per GPU",
         "value": world * steps * n_local / dt_max, "unit": "crosses/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[3]: {n_total} individuals x 100k markers over {world} GPU(s), 8192 per rank, "
+            "workload": f"BASELINE configs[3]: {n_total} individuals x 100k markers over {world} GPU(s), {n_local} per rank, "
                         f"top-{k} by GEBV, every rank crosses its shard from the replicated winners",
             "n_markers": M, "crosses_per_step_per_gpu": n_local, "storage": "bits",
             "collectives": f"all-gather of {min(k, n_local)} (score, index) candidates per rank; one all-gather of the "
@@ -617,6 +618,18 @@ def bench_c4_one_rank(steps, warmup, barrier):
            "unit": line["unit"], "bytes_per_generation": line["bytes_per_generation_per_gpu"], "bound": line["bound"],
            "note": "ONE rank's share, measured on one GPU; the 8-rank run (bench.py --gpus 8 --mode population) adds the two "
                    "all-gathers over RCCL, which no 1-GPU run can time"}
+    # ... and the WHOLE population of configs[3] on this one device (1.6 GB of bit planes; the byte rows it is loaded from
+    # 13.1 GB): the generation the eight ranks compute between them -- GEBV of 65,536, top-6,553, the winners' pool, 65,536
+    # crosses of one flat key split -- with no exchange step, because nothing has to be exchanged
+    torch.cuda.empty_cache()
+    w = population_generation(max(5, steps // 2), 2, 0, 1, torch.cuda.current_device(), False, barrier, n_local=65_536)
+    out["whole_population_on_one_gpu"] = {
+        "workload": w["config"]["workload"], "ms_per_generation": w["ms_per_step"], "value": w["value"], "unit": w["unit"],
+        "generations": w["steps"], "bound": w["bound"],
+        "note": "all 65,536 individuals x 100k markers on ONE MI355X, world_size = 1: what configs[3] asks eight GPUs for fits "
+                "one many times over as bit planes; per generation 8 x one rank's Threefry work and no collective",
+    }
+    torch.cuda.empty_cache()
     eng = HipEngine(np.full(64, 0.01, np.float32), np.ones((64, 1), np.float32))
     n, k, nc = 65_536, 6_553, 8_192
     scores = torch.randn((1, n), device=eng.device)

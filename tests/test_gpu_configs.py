@@ -516,6 +516,73 @@ def test_c4_one_ranks_generation_full_shape():
         assert gebv_close(g.cpu().numpy()[sample], co.gebv(ref, eff, want64=True)[1])
 
 
+@pytest.mark.timeout(900)
+def test_c4_whole_population_on_one_device():
+    """BASELINE configs[3]'s WHOLE population on one device (288 GB of HBM hold it many times over): 65,536 x 100k as
+    bit planes (1.6 GB), its GEBV, the top-6553 of 65,536 with exact ties, the winners' pool, and all 65,536 crosses of
+    one split(key, 2 x 65,536 + 1) in ONE call -- the generation the eight shards of the population-sharded flow compute
+    between them (tests/test_distributed.py: N ranks == one device), at the largest sizes the BASELINE names.  Two
+    generations (the second reads masks made ahead); sampled crosses from both ends, the middle and across the row where
+    byte offsets pass 2^32 against the oracle's meiosis for exactly those keys.  The same generation as byte rows is a
+    13.1 GB block: its rows on either side of 4 GiB and 8 GiB equal the rows expanded one by one."""
+    from breedgym_amd import HipEngine
+    from breedgym_amd.synthetic import synthetic_genetic_map, synthetic_genotypes
+
+    n_total, M, k = 65_536, 100_000, 6553
+    gm = synthetic_genetic_map(M, n_chr=21, n_traits=1, seed=1)
+    r, eff = gm.recombination_vec, gm.marker_effects
+    base = synthetic_genotypes(1024, M, seed=7).view(np.uint8)
+    rng = np.random.default_rng(21)
+    pick = rng.integers(0, 1024, n_total, dtype=np.int32)
+    eng = HipEngine(r, eff)
+    co.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    base_p = eng.pack(eng.upload_population(base))
+    pop = eng.empty_packed(n_total)
+    g = eng.empty((n_total, 1), torch.float32)
+    eng.gather_packed(base_p, torch.from_numpy(pick).to(eng.device), n_total, pop, None, g)
+    g64 = co.gebv(base, eff, want64=True)[1][pick]
+    assert gebv_close(g.cpu().numpy(), g64)
+    scores = g[:, 0].contiguous()
+    best = eng.topk(scores, k).cpu().numpy()
+    assert np.array_equal(best, co.topk(scores.cpu().numpy(), k))  # ties (repeated rows) fall to the lower index
+    pool = eng.empty_packed(k)
+    eng.gather_packed(pop, torch.from_numpy(best.astype(np.int32)).to(eng.device), k, pool)
+    winners = pick[best]  # rows of `base`
+    del pop
+    key, refkey = co.key_from_seed(11).copy(), co.key_from_seed(11)
+    row_4g = (1 << 32) // (2 * M)  # the byte-layout row in which offsets pass 4 GiB
+    for gen in range(2):
+        pairs = rng.integers(0, k, (n_total, 2), dtype=np.int32)
+        outp = eng.empty_packed(n_total)
+        eng.cross_packed(pool, 1, k, torch.from_numpy(pairs).to(eng.device).reshape(1, -1, 2), n_total, key, 1, outp, None, g)
+        keys = co.split(refkey, 2 * n_total + 1)
+        refkey = keys[0].copy()
+        assert np.array_equal(key, refkey)
+        sample = np.unique(np.concatenate(([0, 1, row_4g - 1, row_4g, row_4g + 1, n_total // 2, n_total - 2, n_total - 1],
+                                           rng.integers(0, n_total, 24))))
+        sample_d = torch.from_numpy(sample).to(eng.device)
+        got_rows = eng.unpack(outp[sample_d].contiguous())
+        got = eng.download_population(got_rows).view(np.uint8)
+        ref = np.empty((len(sample), M, 2), np.uint8)
+        for j, b in enumerate(sample):
+            for p in range(2):
+                gk = keys[1 + 2 * int(b) + p]
+                mask = co.meiosis_mask(co.split(gk, 2)[0], r)
+                ref[j, :, p] = base[winners[pairs[b, p]]][np.arange(M), mask]
+        assert np.array_equal(got, ref), f"generation {gen}"
+        assert gebv_close(g.cpu().numpy()[sample], co.gebv(ref, eff, want64=True)[1])
+        if gen == 1:
+            whole = eng.unpack(outp)  # (65,536, 200,000) bytes: 13.1 GB, offsets to 2^33.6
+            assert whole.shape[0] == n_total and whole.numel() > (1 << 33)
+            assert torch.equal(whole[sample_d], got_rows)
+            gb = eng.empty((n_total, 1), torch.float32)
+            eng.gebv(whole, gb)  # the one-pass byte-row GEBV over the same 13.1 GB
+            assert gebv_close(gb.cpu().numpy()[sample], co.gebv(ref, eff, want64=True)[1])
+            assert torch.equal(eng.pack(whole)[:, : M // 4], outp[:, : M // 4])  # ... and back: the bit planes it came from
+            del whole
+        del outp
+
+
 # ---- many long rows: the stream-per-lane mask role + mask_finish_kernel (csrc/mask_stream.h) --------------
 
 
