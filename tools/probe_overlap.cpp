@@ -46,10 +46,12 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 2000;
-  const int64_t M = 10000, E = 16, n = 256;
+  const int max_parts = argc > 2 ? atoi(argv[2]) : 4;  // 1: only the single launch per generation (timing variants of the library)
+  const int64_t M = 10000, E = argc > 3 ? atoll(argv[3]) : 16, n = 256;  // E: envs of the whole batch
   std::vector<float> r(M, 0.0015f), eff(M, 1.0f);
   for (int64_t m = 0; m < M; m += M / 10) r[m] = 0.5f;
   for (int P : {1, 2, 4, 1}) {
+    if (P > max_parts) continue;
     std::vector<Part> parts(P);
     for (auto &p : parts) if (p.make(M, E / P, n, P > 1, r, eff)) { printf("setup: %s\n", bh_last_error()); return 1; }
     for (int i = 0; i < 3000; ++i) {  // clocks settled, masks made ahead
@@ -62,7 +64,7 @@ int main(int argc, char **argv) {
     const double t1 = now();
     hipDeviceSynchronize();
     const double t2 = now();
-    printf("%d part(s) of %2lld envs x %lld: %6.2f us per generation of all 16 envs (host issue %5.2f), %6.1f M crosses/s\n", P,
+    printf("%d part(s) of %2lld envs x %lld: %6.2f us per generation of all envs (host issue %5.2f), %6.1f M crosses/s\n", P,
            (long long)(E / P), (long long)n, (t2 - t0) / reps * 1e6, (t1 - t0) / reps * 1e6, E * n * reps / (t2 - t0) / 1e6);
     if (P > 1) {  // one part alone: what a launch of 1/P of the crosses takes
       hipDeviceSynchronize();
