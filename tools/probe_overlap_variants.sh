@@ -9,6 +9,8 @@
 #   depflags   + every row wave stores the launch number into its own flag word at its end; wave 0 of a workgroup
 #              polls the 128 flag words of its env (one 512-byte read) in front of the first parent words, the other
 #              row waves wait for it in LDS
+#   depfence   + agent-scope release / acquire fences around the flags (at the end of this file; depfenceR / depfenceA:
+#              only the one or the other, built by hand the same way) -- 175 / 164 / 30 us: fences per wave are out
 # run on the GPU box:   tools/_ab/<name>/driver 3000 1 16     (generations, only the one-launch arrangement, envs)
 set -e
 cd "$(dirname "$0")/.."
@@ -32,3 +34,12 @@ tools/ab_build.sh depflags --driver tools/probe_overlap.cpp \
   's|^struct PackedParams \{|static __device__ unsigned ab_flags[8192];\nstruct PackedParams {\n  unsigned ab_expect;|' \
   "s|^      Words wa, wb;\$|      if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __shared__ unsigned ab_flag; if (wave == 0) { const unsigned *f = ab_flags + (unsigned)(block / 32) * 128u; for (int spin = 0; spin < (1 << 12); ++spin) { const unsigned a = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (__all(a >= p.ab_expect \&\& b >= p.ab_expect)) break; __builtin_amdgcn_s_sleep(8); } $LDS_GO } $LDS_WAIT }\n      Words wa, wb;|" \
   "s|$DONE_AT|\1\n    if constexpr (MODE == MODE_CROSS \&\& DIGLDS) if (lane == 0) __hip_atomic_store(ab_flags + (unsigned)block * 4u + (unsigned)wave, p.ab_expect + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);|"
+
+# depfence = depflags + what the memory model asks for around the flags: an agent-scope RELEASE fence in front of a row
+# wave's flag store (its rows -- plain stores for the state, write-through for the observation -- visible to the other
+# XCDs) and an agent-scope ACQUIRE fence behind the wait of every row wave (the parents' rows not out of this XCD's L2)
+tools/ab_build.sh depfence --driver tools/probe_overlap.cpp \
+  "s|$LAUNCH|static unsigned ab_launch = 0; rp.ab_expect = ab_launch++; hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, ab_stream(), rp, mp, fp, gp);|" "$STREAMS" \
+  's|^struct PackedParams \{|static __device__ unsigned ab_flags[8192];\nstruct PackedParams {\n  unsigned ab_expect;|' \
+  "s|^      Words wa, wb;\$|      if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __shared__ unsigned ab_flag; if (wave == 0) { const unsigned *f = ab_flags + (unsigned)(block / 32) * 128u; for (int spin = 0; spin < (1 << 12); ++spin) { const unsigned a = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (__all(a >= p.ab_expect \&\& b >= p.ab_expect)) break; __builtin_amdgcn_s_sleep(8); } $LDS_GO } $LDS_WAIT __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\"); }\n      Words wa, wb;|" \
+  "s|$DONE_AT|\1\n    if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"agent\"); if (lane == 0) __hip_atomic_store(ab_flags + (unsigned)block * 4u + (unsigned)wave, p.ab_expect + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }|"
