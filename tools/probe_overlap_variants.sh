@@ -43,3 +43,22 @@ tools/ab_build.sh depfence --driver tools/probe_overlap.cpp \
   's|^struct PackedParams \{|static __device__ unsigned ab_flags[8192];\nstruct PackedParams {\n  unsigned ab_expect;|' \
   "s|^      Words wa, wb;\$|      if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __shared__ unsigned ab_flag; if (wave == 0) { const unsigned *f = ab_flags + (unsigned)(block / 32) * 128u; for (int spin = 0; spin < (1 << 12); ++spin) { const unsigned a = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (__all(a >= p.ab_expect \&\& b >= p.ab_expect)) break; __builtin_amdgcn_s_sleep(8); } $LDS_GO } $LDS_WAIT __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\"); }\n      Words wa, wb;|" \
   "s|$DONE_AT|\1\n    if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"agent\"); if (lane == 0) __hip_atomic_store(ab_flags + (unsigned)block * 4u + (unsigned)wave, p.ab_expect + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }|"
+
+# depsc1 = depflags + coherence on the rows themselves instead of fences: the state rows stored as relaxed agent-scope
+# atomics (global_store_short sc1: write-through) with s_waitcnt vmcnt(0) in front of the wave's flag store (the flag
+# only once the rows are out), the parents' words loaded as relaxed agent-scope atomics (global_load_ushort sc1: past
+# this XCD's L2; the mask words stay plain loads -- masks made two generations ahead would have a kernel boundary
+# between maker and reader).  depsc1S: only the stores + the wait; depsc1L: only the loads.
+WAITHEAD="      if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __shared__ unsigned ab_flag; if (wave == 0) { const unsigned *f = ab_flags + (unsigned)(block / 32) * 128u; for (int spin = 0; spin < (1 << 12); ++spin) { const unsigned a = __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(f + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (__all(a >= p.ab_expect \&\& b >= p.ab_expect)) break; __builtin_amdgcn_s_sleep(8); } $LDS_GO } $LDS_WAIT"
+FLAG="if (lane == 0) __hip_atomic_store(ab_flags + (unsigned)block * 4u + (unsigned)wave, p.ab_expect + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);"
+SC1LOAD='__hip_atomic_load(reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(\1) + 2u * (uint32_t)v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)'
+SC1STORE='s|^          \*reinterpret_cast<uint16_t \*>\(reinterpret_cast<char \*>\(dstp\[r\]\) \+ 2u \* \(uint32_t\)vu\) = \(uint16_t\)o;|          __hip_atomic_store(reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(dstp[r]) + 2u * (uint32_t)vu), (uint16_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);|'
+for v in depsc1 depsc1S depsc1L; do
+  edits=("s|$LAUNCH|static unsigned ab_launch = 0; rp.ab_expect = ab_launch++; hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, ab_stream(), rp, mp, fp, gp);|" "$STREAMS"
+         's|^struct PackedParams \{|static __device__ unsigned ab_flags[8192];\nstruct PackedParams {\n  unsigned ab_expect;|'
+         "s|^      Words wa, wb;\$|$WAITHEAD }\n      Words wa, wb;|"
+         "s|$DONE_AT|\1\n    if constexpr (MODE == MODE_CROSS \&\& DIGLDS) { __builtin_amdgcn_s_waitcnt(0x0F70); $FLAG }|")
+  [ $v != depsc1S ] && edits+=("s|word_at\((src[01]\[r\]), \(uint32_t\)v\)|$SC1LOAD|")
+  [ $v != depsc1L ] && edits+=("$SC1STORE")
+  tools/ab_build.sh $v --driver tools/probe_overlap.cpp "${edits[@]}"
+done
