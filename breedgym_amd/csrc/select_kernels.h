@@ -77,6 +77,9 @@ __device__ __forceinline__ int32_t *shuffle_lds(u32x2 k, int N, int P, int round
                                                 int32_t *y, int layout) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < N; i += nt) x[i] = i;
+  // (zero rounds -- N = 1: SelectionScores with k = 2 has ONE pair -- return x as it stands: without this barrier the
+  // other waves read x[0] before wave 0 has written it; profiles/r05_fuzz_env_mismatch.txt)
+  if (rounds == 0) __syncthreads();
   const int L = N + (N & 1), h = L >> 1;
   for (int rd = 0; rd < rounds; ++rd) {
     const u32x2 nk = split_at(k.x, k.y, 2u, 0u, layout), sub = split_at(k.x, k.y, 2u, 1u, layout);

@@ -69,6 +69,26 @@ def test_selection_actions_large(E, n, k, nc, layout, rng):
     assert np.array_equal(key, refkey)
 
 
+@pytest.mark.parametrize("E,n", [(5, 785), (3, 2000), (6, 130)])
+def test_selection_actions_of_one_pair_many_times(E, n, layout, rng):
+    """k = 2: ONE diallel pair, JAX's shuffle of one element has zero rounds, and every slot of the generation takes
+    that pair.  `shuffle_lds` returned the identity it had just written without a barrier: the waves behind the first
+    read perm[0] before it was there -- rows [64, blockDim) of an env crossed from whatever LDS held, about once in a
+    few hundred calls (profiles/r05_fuzz_env_mismatch.txt, found by tools/fuzz_env.py).  Many calls, dirty LDS in
+    between (a founder draw of another size), every one against the oracle."""
+    eng = tiny_engine(layout)
+    key = co.key_from_seed(77)
+    for it in range(300):
+        s = np.round(rng.normal(0, 2, (E, n)), 1).astype(np.float32)  # scores with ties
+        ref, refkey = co.selection_actions(s, 2, 1, key)
+        got, key2 = eng.selection_actions(torch.from_numpy(s), 2, 1, key)
+        assert np.array_equal(got.cpu().numpy(), ref), (E, n, it)
+        assert np.array_equal(key2, refkey)
+        key = refkey
+        if it % 3 == 0:
+            eng.founders(key, 2, 500 + it, 200)  # something else through the same CUs' LDS
+
+
 def test_selection_actions_large_through_the_env_window(rng):
     eng = tiny_engine("original")
     E, n, k, nc = 5, 2048, 204, 1024
