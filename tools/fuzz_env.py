@@ -136,7 +136,11 @@ def one_case(case):
         if roll < 0.72:
             if wrap_k:
                 sc = np.round(rng.normal(0, 2, (E, n)), int(rng.integers(0, 3))).astype(np.float32)  # scores with ties
+                key_before = env_key
                 a, env_key = co.selection_actions(sc, wrap_k, wrap_nc, env_key)
+                # the actions themselves, not only what comes of them (the same conversion the wrapper is about to make)
+                got_a, _ = env.simulator.engine.selection_actions(sc, wrap_k, wrap_nc, key_before)
+                assert np.array_equal(got_a.cpu().numpy(), a), what + f": event {ev}: SelectionScores' actions"
                 pop, rews, ter, tru, info = stepper.step(sc)
             else:
                 a = rng.integers(0, n, (E, n, 2), dtype=np.int32)
